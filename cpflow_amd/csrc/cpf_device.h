@@ -1,0 +1,622 @@
+// cpflow_amd device code: one workgroup optimises one sample (one CP-template start).
+//
+// Replaces, per optimiser step, what XLA runs for the reference's
+//   build_unitary            cpflow/main.py:106-146   (gates.py:22-58, circuit_assembly.py:31-45)
+//   cost_HST                 cpflow/matrix_utils.py:35-42
+//   regularization_func      cpflow/main.py:563-564   (penalty.py:44-71)
+//   value_and_grad           cpflow/optimization.py:340
+//   optax_update_step + best tracking   cpflow/optimization.py:14-25, 61-75
+// with a single persistent kernel: all T iterations of a sample run inside one launch.
+//
+// Data layout (gfx950, wave64).  The 2^n x 2^n unitary U (and its loss cotangent C) is
+// spread over the 64*WPS threads of the workgroup, columns first:
+//   column bits -> wave bits, then lane bits {5,4,2,3,1,0}   (columns never interact)
+//   row bits    -> remaining lane bits {0,1,3,2,..} (DPP-reachable), then register bits
+// A gate acts on ROW bits only: on a register bit it is pure in-register arithmetic, on a
+// lane bit the partner amplitude comes over DPP (quad_perm / row_ror / row_shl+shr), never
+// through LDS.  Gate coefficients (cos, sin) are wave-uniform: computed once per step by
+// the parameter's owner thread and broadcast through LDS.
+//
+// Gradient: adjoint sweep.  After the forward pass psi = U(theta) and C = dL/dU* are walked
+// backwards through the gate list; for a rotation exp(-i a sigma/2) the derivative is
+// (1/2) sum Im(conj(C) sigma psi) taken right after the gate, then both psi and C are
+// multiplied by the gate's inverse.  No intermediate unitaries are stored.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cpf {
+
+enum : int { OP_RX = 0, OP_RY = 1, OP_RZ = 2, OP_CP = 3, OP_CZ = 4 };
+enum : int { MODE_OPTIMIZE = 0, MODE_LOSS_GRAD = 1, MODE_UNITARY = 2 };
+
+struct Piece { float lo, hi, slope, icpt; };
+
+struct KArgs {
+    const int4* prog;          // [G] {kind, q0, q1, param}
+    int G, P, T, mode;
+    int n_actual;              // problem qubits (<= kernel qubits; spectators are the low bits)
+    const float2* target;      // [D][D] embedded target, D = 2^NQ
+    const uint8_t* pkind;      // [P] 1 = CP angle (full angle, penalised), 0 = rotation (half angle)
+    const float2* bias;        // [T] {1 - b1^t, 1 - b2^t}, t = 1..T
+    Piece pc[10];
+    int pen_kind, use_reg;
+    float r, lr, b1, b2, eps, omb1, omb2, thr_cp, entry_loss, inv_dim2;
+    const float* init;         // [S][P]
+    const uint8_t* frozen;     // [S][P] or null
+    float* out_params;         // [S][2][P]
+    float* out_regloss;        // [S][2]   (MODE_LOSS_GRAD: [S])
+    float* out_loss;           // [S][2]   (MODE_LOSS_GRAD: [S])
+    float* out_reg;            // [S][2]   (MODE_LOSS_GRAD: [S])
+    int32_t* out_cz;           // [S]
+    uint8_t* out_pass;         // [S]
+    float* hist_params;        // [S][T][P] or null
+    float* hist_loss;          // [S][T] or null
+    float* out_grad;           // MODE_LOSS_GRAD: [S][P] or null
+    float2* out_U;             // MODE_UNITARY: [S][N][N]
+};
+
+// ------------------------------------------------------------------ layout
+template <int NQ_, int LW_>
+struct Lay {
+    static constexpr int NQ = NQ_, LW = LW_;
+    static constexpr int WPS = 1 << LW;
+    static constexpr int THREADS = 64 * WPS;
+    static constexpr int D = 1 << NQ;
+    static constexpr int NLC = NQ - LW;                          // column bits on lanes
+    static constexpr int NLR = (6 - NLC) < NQ ? (6 - NLC) : NQ;  // row bits on lanes
+    static constexpr int NRR = NQ - NLR;                         // row bits in registers
+    static constexpr int E = 1 << NRR;                           // complex elements per thread
+    static_assert(NLC >= 0 && NLC <= 6, "too many column bits for one wave");
+    static_assert(NLC + NLR == 6, "layout must use all 64 lanes");
+    __host__ __device__ static constexpr int row_lane_bit(int i) {
+        constexpr int t[6] = {0, 1, 3, 2, 4, 5};
+        return t[i];
+    }
+    __host__ __device__ static constexpr int col_lane_bit(int i) {
+        constexpr int t[6] = {5, 4, 2, 3, 1, 0};
+        return t[i];
+    }
+    __host__ __device__ static constexpr bool row_on_lane(int q) { return q < NLR; }
+    __host__ __device__ static constexpr int row_bit(int q) { return q < NLR ? row_lane_bit(q) : q - NLR; }
+    // row / column index (qubit 0 = most significant bit) of element e of (wave, lane)
+    __device__ static int row_index(int lane, int e) {
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            int b = row_on_lane(q) ? ((lane >> row_bit(q)) & 1) : ((e >> row_bit(q)) & 1);
+            r |= b << (NQ - 1 - q);
+        }
+        return r;
+    }
+    __device__ static int col_index(int lane, int wave) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            int b = q < LW ? ((wave >> q) & 1) : ((lane >> col_lane_bit(q - LW)) & 1);
+            c |= b << (NQ - 1 - q);
+        }
+        return c;
+    }
+};
+
+// ------------------------------------------------------------------ cross-lane helpers
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, ROW_MASK,
+                                                      BANK_MASK, false));
+}
+// value held by lane (lane ^ (1 << BIT))
+template <int BIT>
+__device__ __forceinline__ float xor_lane(float x) {
+    if constexpr (BIT == 0) return dpp<0xB1>(x, x);          // quad_perm:[1,0,3,2]
+    else if constexpr (BIT == 1) return dpp<0x4E>(x, x);     // quad_perm:[2,3,0,1]
+    else if constexpr (BIT == 3) return dpp<0x128>(x, x);    // row_ror:8
+    else if constexpr (BIT == 2) {
+        float t = dpp<0x104, 0xF, 0x5>(x, x);                // row_shl:4 -> banks 0,2 read lane+4
+        return dpp<0x114, 0xF, 0xA>(t, x);                   // row_shr:4 -> banks 1,3 read lane-4
+    } else return __shfl_xor(x, 1 << BIT);
+}
+// sum over the 64 lanes, returned wave-uniform; fixed order => run-to-run deterministic
+__device__ __forceinline__ float wave_sum(float x) {
+    x += dpp<0xB1>(x, x);
+    x += dpp<0x4E>(x, x);
+    x += dpp<0x124>(x, x);                                   // row_ror:4
+    x += dpp<0x128>(x, x);                                   // row_ror:8 -> every lane holds its row total
+    x += dpp<0x142, 0xA, 0xF>(0.f, x);                       // row_bcast:15 into rows 1,3
+    x += dpp<0x143, 0xC, 0xF>(0.f, x);                       // row_bcast:31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// ------------------------------------------------------------------ per-thread state
+template <class L>
+struct State {
+    float pr[L::E], pi[L::E];      // psi  (the unitary being built / un-built)
+    float cr[L::E], ci[L::E];      // C    (cotangent of the loss, scaled by 1/2)
+    float sg[L::NLR > 0 ? L::NLR : 1];   // +1 if this lane's bit of lane-row-qubit i is set, else -1
+    bool lb[L::NLR > 0 ? L::NLR : 1];
+};
+
+// ---- rotations: forward / inverse application to one matrix (re, im)
+// s is sin(a/2) for the forward gate, -sin(a/2) for the inverse.
+template <class L, int KIND, int Q>
+__device__ __forceinline__ void rot_apply(float (&re)[L::E], float (&im)[L::E], float c, float s, const State<L>& st) {
+    constexpr int BIT = L::row_bit(Q);
+    if constexpr (L::row_on_lane(Q)) {
+        const float ss = st.sg[Q] * s;
+#pragma unroll
+        for (int e = 0; e < L::E; e++) {
+            float nr, ni;
+            if constexpr (KIND == OP_RX) {
+                float qr = xor_lane<BIT>(re[e]), qi = xor_lane<BIT>(im[e]);
+                nr = fmaf(s, qi, c * re[e]);
+                ni = fmaf(-s, qr, c * im[e]);
+            } else if constexpr (KIND == OP_RY) {
+                float qr = xor_lane<BIT>(re[e]), qi = xor_lane<BIT>(im[e]);
+                nr = fmaf(ss, qr, c * re[e]);
+                ni = fmaf(ss, qi, c * im[e]);
+            } else {
+                nr = fmaf(-ss, im[e], c * re[e]);
+                ni = fmaf(ss, re[e], c * im[e]);
+            }
+            re[e] = nr; im[e] = ni;
+        }
+    } else {
+#pragma unroll
+        for (int e0 = 0; e0 < L::E; e0++) {
+            if (e0 & (1 << BIT)) continue;
+            const int e1 = e0 | (1 << BIT);
+            float r0 = re[e0], i0 = im[e0], r1 = re[e1], i1 = im[e1];
+            if constexpr (KIND == OP_RX) {
+                re[e0] = fmaf(s, i1, c * r0);  im[e0] = fmaf(-s, r1, c * i0);
+                re[e1] = fmaf(s, i0, c * r1);  im[e1] = fmaf(-s, r0, c * i1);
+            } else if constexpr (KIND == OP_RY) {
+                re[e0] = fmaf(-s, r1, c * r0); im[e0] = fmaf(-s, i1, c * i0);
+                re[e1] = fmaf(s, r0, c * r1);  im[e1] = fmaf(s, i0, c * i1);
+            } else {
+                re[e0] = fmaf(s, i0, c * r0);  im[e0] = fmaf(-s, r0, c * i0);
+                re[e1] = fmaf(-s, i1, c * r1); im[e1] = fmaf(s, r1, c * i1);
+            }
+        }
+    }
+}
+
+// ---- rotations: derivative contribution, evaluated with psi, C right after the gate.
+// Returns this thread's share of  sum Im(conj(C) sigma psi)   (C carries the factor 1/2).
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float rot_grad(const State<L>& st) {
+    constexpr int BIT = L::row_bit(Q);
+    float u = 0.f;
+    if constexpr (L::row_on_lane(Q)) {
+#pragma unroll
+        for (int e = 0; e < L::E; e++) {
+            if constexpr (KIND == OP_RX) {
+                float qr = xor_lane<BIT>(st.pr[e]), qi = xor_lane<BIT>(st.pi[e]);
+                u = fmaf(st.cr[e], qi, u); u = fmaf(-st.ci[e], qr, u);
+            } else if constexpr (KIND == OP_RY) {
+                float qr = xor_lane<BIT>(st.pr[e]), qi = xor_lane<BIT>(st.pi[e]);
+                u = fmaf(st.cr[e], qr, u); u = fmaf(st.ci[e], qi, u);
+            } else {
+                u = fmaf(st.cr[e], st.pi[e], u); u = fmaf(-st.ci[e], st.pr[e], u);
+            }
+        }
+        if constexpr (KIND == OP_RX) return u;
+        else if constexpr (KIND == OP_RY) return st.sg[Q] * u;
+        else return -st.sg[Q] * u;
+    } else {
+#pragma unroll
+        for (int e0 = 0; e0 < L::E; e0++) {
+            if (e0 & (1 << BIT)) continue;
+            const int e1 = e0 | (1 << BIT);
+            if constexpr (KIND == OP_RX) {
+                u = fmaf(st.cr[e0], st.pi[e1], u); u = fmaf(-st.ci[e0], st.pr[e1], u);
+                u = fmaf(st.cr[e1], st.pi[e0], u); u = fmaf(-st.ci[e1], st.pr[e0], u);
+            } else if constexpr (KIND == OP_RY) {
+                u = fmaf(-st.cr[e0], st.pr[e1], u); u = fmaf(-st.ci[e0], st.pi[e1], u);
+                u = fmaf(st.cr[e1], st.pr[e0], u);  u = fmaf(st.ci[e1], st.pi[e0], u);
+            } else {
+                u = fmaf(st.cr[e0], st.pi[e0], u);  u = fmaf(-st.ci[e0], st.pr[e0], u);
+                u = fmaf(-st.cr[e1], st.pi[e1], u); u = fmaf(st.ci[e1], st.pr[e1], u);
+            }
+        }
+        return u;
+    }
+}
+
+// ---- controlled phase diag(1,1,1,e^{ia}) on qubits Q0 < Q1 (symmetric in its qubits)
+template <class L, int Q0, int Q1>
+__device__ __forceinline__ bool cp_lane_pred(const State<L>& st) {
+    bool p = true;
+    if constexpr (L::row_on_lane(Q0)) p = p && st.lb[Q0];
+    if constexpr (L::row_on_lane(Q1)) p = p && st.lb[Q1];
+    return p;
+}
+template <class L, int Q0, int Q1>
+__host__ __device__ constexpr bool cp_reg_sel(int e) {
+    bool s = true;
+    if (!L::row_on_lane(Q0)) s = s && ((e >> L::row_bit(Q0)) & 1);
+    if (!L::row_on_lane(Q1)) s = s && ((e >> L::row_bit(Q1)) & 1);
+    return s;
+}
+template <class L, int Q0, int Q1>
+__device__ __forceinline__ void cp_apply(float (&re)[L::E], float (&im)[L::E], float cc, float sc, const State<L>& st) {
+    const bool p = cp_lane_pred<L, Q0, Q1>(st);
+    const float ce = p ? cc : 1.f, se = p ? sc : 0.f;
+#pragma unroll
+    for (int e = 0; e < L::E; e++) {
+        if (!cp_reg_sel<L, Q0, Q1>(e)) continue;
+        float nr = fmaf(-se, im[e], ce * re[e]);
+        float ni = fmaf(se, re[e], ce * im[e]);
+        re[e] = nr; im[e] = ni;
+    }
+}
+// d/da: dU = i |11><11| U  ->  dL/da = -2 sum_{11} (Cr psi_i - Ci psi_r)   (C carries 1/2)
+template <class L, int Q0, int Q1>
+__device__ __forceinline__ float cp_grad(const State<L>& st) {
+    float u = 0.f;
+#pragma unroll
+    for (int e = 0; e < L::E; e++) {
+        if (!cp_reg_sel<L, Q0, Q1>(e)) continue;
+        u = fmaf(st.cr[e], st.pi[e], u); u = fmaf(-st.ci[e], st.pr[e], u);
+    }
+    return cp_lane_pred<L, Q0, Q1>(st) ? -2.f * u : 0.f;
+}
+
+// ------------------------------------------------------------------ dispatch on (kind, qubit)
+#define CPF_Q_SWITCH(q, BODY)                                            \
+    switch (q) {                                                         \
+        case 0: { constexpr int Q = 0; BODY; } break;                    \
+        case 1: { constexpr int Q = 1; BODY; } break;                    \
+        case 2: { constexpr int Q = 2; BODY; } break;                    \
+        case 3: if constexpr (L::NQ > 3) { constexpr int Q = 3; BODY; } break; \
+        case 4: if constexpr (L::NQ > 4) { constexpr int Q = 4; BODY; } break; \
+        case 5: if constexpr (L::NQ > 5) { constexpr int Q = 5; BODY; } break; \
+        default: break;                                                  \
+    }
+
+#define CPF_PAIR_CASE(A, B)                                              \
+    case A * 8 + B: if constexpr (L::NQ > B) { constexpr int Q0 = A, Q1 = B; BODY_PAIR; } break;
+
+// forward application of op to psi
+template <class L>
+__device__ __forceinline__ void op_forward(int kind, int q0, int q1, float c, float s, State<L>& st) {
+    switch (kind) {
+        case OP_RX: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RX, Q>(st.pr, st.pi, c, s, st))); break;
+        case OP_RY: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RY, Q>(st.pr, st.pi, c, s, st))); break;
+        case OP_RZ: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RZ, Q>(st.pr, st.pi, c, s, st))); break;
+        default: {
+            if (kind == OP_CZ) { c = -1.f; s = 0.f; }
+#define BODY_PAIR cp_apply<L, Q0, Q1>(st.pr, st.pi, c, s, st)
+            switch (q0 * 8 + q1) {
+                CPF_PAIR_CASE(0, 1) CPF_PAIR_CASE(0, 2) CPF_PAIR_CASE(1, 2)
+                CPF_PAIR_CASE(0, 3) CPF_PAIR_CASE(1, 3) CPF_PAIR_CASE(2, 3)
+                CPF_PAIR_CASE(0, 4) CPF_PAIR_CASE(1, 4) CPF_PAIR_CASE(2, 4) CPF_PAIR_CASE(3, 4)
+                CPF_PAIR_CASE(0, 5) CPF_PAIR_CASE(1, 5) CPF_PAIR_CASE(2, 5) CPF_PAIR_CASE(3, 5) CPF_PAIR_CASE(4, 5)
+                default: break;
+            }
+#undef BODY_PAIR
+        } break;
+    }
+}
+
+// backward step for op: returns this thread's gradient share, then un-applies the gate on psi and C
+template <class L>
+__device__ __forceinline__ float op_backward(int kind, int q0, int q1, float c, float s, State<L>& st) {
+    float d = 0.f;
+    switch (kind) {
+#define CPF_ROT_BWD(KIND)                                                         \
+        CPF_Q_SWITCH(q0, (d = rot_grad<L, KIND, Q>(st),                           \
+                          rot_apply<L, KIND, Q>(st.pr, st.pi, c, -s, st),         \
+                          rot_apply<L, KIND, Q>(st.cr, st.ci, c, -s, st)))
+        case OP_RX: CPF_ROT_BWD(OP_RX); break;
+        case OP_RY: CPF_ROT_BWD(OP_RY); break;
+        case OP_RZ: CPF_ROT_BWD(OP_RZ); break;
+#undef CPF_ROT_BWD
+        default: {
+            const bool is_cz = (kind == OP_CZ);
+            if (is_cz) { c = -1.f; s = 0.f; }
+#define BODY_PAIR (d = is_cz ? 0.f : cp_grad<L, Q0, Q1>(st),                      \
+                   cp_apply<L, Q0, Q1>(st.pr, st.pi, c, -s, st),                  \
+                   cp_apply<L, Q0, Q1>(st.cr, st.ci, c, -s, st))
+            switch (q0 * 8 + q1) {
+                CPF_PAIR_CASE(0, 1) CPF_PAIR_CASE(0, 2) CPF_PAIR_CASE(1, 2)
+                CPF_PAIR_CASE(0, 3) CPF_PAIR_CASE(1, 3) CPF_PAIR_CASE(2, 3)
+                CPF_PAIR_CASE(0, 4) CPF_PAIR_CASE(1, 4) CPF_PAIR_CASE(2, 4) CPF_PAIR_CASE(3, 4)
+                CPF_PAIR_CASE(0, 5) CPF_PAIR_CASE(1, 5) CPF_PAIR_CASE(2, 5) CPF_PAIR_CASE(3, 5) CPF_PAIR_CASE(4, 5)
+                default: break;
+            }
+#undef BODY_PAIR
+        } break;
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------ penalty (penalty.py:44-71)
+__device__ __forceinline__ float floor_mod_2pi(float a) {
+    const float twopi = 6.2831855f;
+    float r = fmodf(a, twopi);
+    if (r != 0.f && r < 0.f) r += twopi;
+    return r;
+}
+__device__ __forceinline__ float penalty_value(const KArgs& a, float ang, float& slope) {
+    if (a.pen_kind == 1) {                                    // penalty.py:74-76
+        slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
+        return fabsf(ang);
+    }
+    const float x = floor_mod_2pi(ang);
+    float sl = 0.f, ic = 0.f;
+    if (x <= a.pc[0].hi) { sl = a.pc[0].slope; ic = a.pc[0].icpt; }
+#pragma unroll
+    for (int i = 1; i < 10; i++)
+        if (a.pc[i].lo < x && x <= a.pc[i].hi) { sl = a.pc[i].slope; ic = a.pc[i].icpt; }   // last true wins
+    slope = sl;
+    return __fadd_rn(__fmul_rn(sl, x), ic);
+}
+// cp_utils.py:45-50 cz_value
+__device__ __forceinline__ float cz_value(float ang, float t) {
+    const float pi = 3.1415927f, twopi = 6.2831855f;
+    const float x = floor_mod_2pi(ang);
+    float v = 2.f;
+    if (x < t) v = 0.f;
+    if (fabsf(x - twopi) < t) v = 0.f;
+    if (fabsf(x - pi) < t) v = 1.f;
+    return v;
+}
+
+// ------------------------------------------------------------------ workgroup reductions
+template <class L, int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
+    if constexpr (L::WPS > 1) {
+        __syncthreads();                                  // previous readers of red are done
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < L::WPS; w++) s += red[w * NV + k];
+            v[k] = s;
+        }
+    }
+}
+
+__host__ __device__ inline size_t lds_floats(int P, int wps) {
+    // theta, m, v, pen-slope, cs(2), grad slots(wps), reduction scratch
+    return (size_t)P * (6 + wps) + 16 * wps;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int NQ, int LW>
+__global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
+    using L = Lay<NQ, LW>;
+    constexpr int E = L::E;
+    extern __shared__ float smem[];
+    const int P = a.P;
+    float* th = smem;
+    float* mm = th + P;
+    float* vv = mm + P;
+    float* psl = vv + P;                               // r * penalty slope of CP angles
+    float2* cs = reinterpret_cast<float2*>(psl + P);   // (cos, sin) per parameter
+    float* gw = reinterpret_cast<float*>(cs + P);      // [WPS][P] per-wave gradient slots
+    float* red = gw + (size_t)L::WPS * P;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t s_idx = blockIdx.x;
+    const float* init = a.init + s_idx * P;
+    const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
+
+    State<L> st;
+#pragma unroll
+    for (int i = 0; i < L::NLR; i++) {
+        st.lb[i] = (lane >> L::row_lane_bit(i)) & 1;
+        st.sg[i] = st.lb[i] ? 1.f : -1.f;
+    }
+    const int col = L::col_index(lane, wave);
+    float vr[E], vi[E];
+    bool diag[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int row = L::row_index(lane, e);
+        const float2 t = a.target[row * L::D + col];
+        vr[e] = t.x; vi[e] = t.y;
+        diag[e] = (row == col);
+    }
+
+    // owner threads: parameter j lives with thread j % THREADS
+    for (int j = tid; j < P; j += L::THREADS) {
+        const float t0 = init[j];
+        th[j] = t0; mm[j] = 0.f; vv[j] = 0.f;
+        if (a.mode == MODE_OPTIMIZE) {
+            a.out_params[(s_idx * 2 + 0) * P + j] = t0;
+            a.out_params[(s_idx * 2 + 1) * P + j] = t0;
+        }
+        float sn, cn;
+        sincosf(a.pkind[j] ? t0 : 0.5f * t0, &sn, &cn);
+        cs[j] = make_float2(cn, sn);
+    }
+    __syncthreads();
+
+    float best = 0.f, first = 0.f;
+    const int iters = (a.mode == MODE_OPTIMIZE && a.T > 0) ? a.T : 1;
+    for (int it = 0; it < iters; it++) {
+        // ---- forward: psi = G_{G-1} ... G_0
+#pragma unroll
+        for (int e = 0; e < E; e++) { st.pr[e] = diag[e] ? 1.f : 0.f; st.pi[e] = 0.f; }
+        for (int g = 0; g < a.G; g++) {
+            const int4 op = a.prog[g];
+            const float2 c_s = cs[op.w];
+            op_forward<L>(op.x, op.y, op.z, c_s.x, c_s.y, st);
+        }
+        if (a.mode == MODE_UNITARY) {
+            const int d = NQ - a.n_actual, msk = (1 << d) - 1, N = 1 << a.n_actual;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int row = L::row_index(lane, e);
+                if (((row | col) & msk) == 0)
+                    a.out_U[(s_idx * N + (row >> d)) * N + (col >> d)] = make_float2(st.pr[e], st.pi[e]);
+            }
+            return;
+        }
+        // ---- loss (matrix_utils.py:35-42) and penalty (main.py:563-564)
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; e++) {                         // T = sum psi conj(V)
+            acc[0] = fmaf(st.pr[e], vr[e], acc[0]); acc[0] = fmaf(st.pi[e], vi[e], acc[0]);
+            acc[1] = fmaf(st.pi[e], vr[e], acc[1]); acc[1] = fmaf(-st.pr[e], vi[e], acc[1]);
+        }
+        if (a.use_reg) {
+            for (int j = tid; j < P; j += L::THREADS) {
+                if (a.pkind[j]) {
+                    float sl;
+                    acc[2] += penalty_value(a, th[j], sl);
+                    psl[j] = a.r * sl;
+                }
+            }
+        }
+        block_sum<L, 3>(acc, red, wave, lane);
+        const float tr = acc[0], ti = acc[1];
+        const float ab = sqrtf(fmaf(tr, tr, ti * ti));
+        const float loss = 1.f - ab * ab * a.inv_dim2;
+        const float reg = a.use_reg ? a.r * acc[2] : 0.f;
+        const float regloss = loss + reg;
+
+        if (a.mode == MODE_OPTIMIZE) {
+            // best-so-far tracking on the PRE-update angles, strict < (optimization.py:70-73)
+            bool improved = false;
+            if (it == 0) { first = regloss; best = regloss; }
+            else if (regloss < best) { best = regloss; improved = true; }
+            if (improved || a.hist_params) {
+                for (int j = tid; j < P; j += L::THREADS) {
+                    const float t = th[j];
+                    if (improved) a.out_params[(s_idx * 2 + 1) * P + j] = t;
+                    if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + j] = t;
+                }
+            }
+            if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
+            if (a.T == 0) break;
+        } else {
+            if (tid == 0) { a.out_loss[s_idx] = loss; a.out_reg[s_idx] = reg; a.out_regloss[s_idx] = regloss; }
+            if (!a.out_grad) return;
+        }
+
+        // ---- backward sweep.  C = (1/2) dL/dU* = -(1/D^2) T V
+        {
+            const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                st.cr[e] = fmaf(fr, vr[e], -fi * vi[e]);
+                st.ci[e] = fmaf(fr, vi[e], fi * vr[e]);
+            }
+        }
+        for (int g = a.G - 1; g >= 0; g--) {
+            const int4 op = a.prog[g];
+            const float2 c_s = cs[op.w];
+            float d = op_backward<L>(op.x, op.y, op.z, c_s.x, c_s.y, st);
+            if (op.x != OP_CZ) {
+                d = wave_sum(d);
+                if (lane == 0) gw[wave * P + op.w] = d;
+            }
+        }
+        __syncthreads();
+
+        // ---- Adam (optax 0.1.1 scale_by_adam + scale(-lr)), owners only
+        if (a.mode == MODE_LOSS_GRAD) {
+            for (int j = tid; j < P; j += L::THREADS) {
+                float g = 0.f;
+#pragma unroll
+                for (int w = 0; w < L::WPS; w++) g += gw[w * P + j];
+                if (a.use_reg && a.pkind[j]) g += psl[j];
+                a.out_grad[s_idx * P + j] = g;
+            }
+            return;
+        }
+        const float2 bc = a.bias[it];
+        for (int j = tid; j < P; j += L::THREADS) {
+            float g = 0.f;
+#pragma unroll
+            for (int w = 0; w < L::WPS; w++) g += gw[w * P + j];
+            if (a.use_reg && a.pkind[j]) g += psl[j];
+            if (frozen && frozen[j]) continue;
+            const float m = fmaf(a.b1, mm[j], a.omb1 * g);
+            const float v = fmaf(a.b2, vv[j], a.omb2 * (g * g));
+            mm[j] = m; vv[j] = v;
+            const float mh = m / bc.x, vh = v / bc.y;
+            const float t = fmaf(-a.lr, mh / (sqrtf(vh) + a.eps), th[j]);
+            th[j] = t;
+            float sn, cn;
+            sincosf(a.pkind[j] ? t : 0.5f * t, &sn, &cn);
+            cs[j] = make_float2(cn, sn);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370);
+    //      argmin, CZ count, entry-loss flag (cp_utils.py:144-164, 193-198)
+    const int bi = (best < first) ? 1 : 0;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = tid; j < P; j += L::THREADS) {
+        if (a.pkind[j]) {
+            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j];
+            const float t1 = a.out_params[(s_idx * 2 + 1) * P + j];
+            float sl;
+            if (a.use_reg) { acc[0] += penalty_value(a, t0, sl); acc[1] += penalty_value(a, t1, sl); }
+            acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
+        }
+    }
+    block_sum<L, 3>(acc, red, wave, lane);
+    if (tid == 0) {
+        const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
+        const float l0 = first - reg0, l1 = best - reg1;
+        a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
+        a.out_reg[s_idx * 2 + 0] = reg0;      a.out_reg[s_idx * 2 + 1] = reg1;
+        a.out_loss[s_idx * 2 + 0] = l0;       a.out_loss[s_idx * 2 + 1] = l1;
+        a.out_cz[s_idx] = (int32_t)acc[2];
+        a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ initial angles (jax threefry2x32)
+// Restates what jax.random does for  main.py:541-548 / cp_utils.py:31-35 / trigonometric_utils.py:35-38:
+//   keys = split(PRNGKey(seed), S+1)[1:];  angles[j] = uniform(split(keys[j])[1], (P,), 0, 2*pi)
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+    const uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;
+    x0 += ks0; x1 += ks1;
+#define CPF_TF_R(r) { x0 += x1; x1 = rotl32(x1, r); x1 ^= x0; }
+    CPF_TF_R(13) CPF_TF_R(15) CPF_TF_R(26) CPF_TF_R(6)   x0 += ks1; x1 += ks2 + 1u;
+    CPF_TF_R(17) CPF_TF_R(29) CPF_TF_R(16) CPF_TF_R(24)  x0 += ks2; x1 += ks0 + 2u;
+    CPF_TF_R(13) CPF_TF_R(15) CPF_TF_R(26) CPF_TF_R(6)   x0 += ks0; x1 += ks1 + 3u;
+    CPF_TF_R(17) CPF_TF_R(29) CPF_TF_R(16) CPF_TF_R(24)  x0 += ks1; x1 += ks2 + 4u;
+    CPF_TF_R(13) CPF_TF_R(15) CPF_TF_R(26) CPF_TF_R(6)   x0 += ks2; x1 += ks0 + 5u;
+#undef CPF_TF_R
+}
+// element i of threefry_2x32(key, iota(n)) (counts padded to even, split in halves)
+__device__ __forceinline__ uint32_t random_bits_at(uint32_t k0, uint32_t k1, uint32_t n, uint32_t i) {
+    const uint32_t h = (n + 1u) >> 1, lo = (i < h) ? i : i - h, hi = lo + h;
+    uint32_t x0 = lo, x1 = (hi < n) ? hi : 0u;
+    threefry2x32(k0, k1, x0, x1);
+    return (i < h) ? x0 : x1;
+}
+__global__ void k_initial_angles(uint32_t seed, uint32_t s_total, uint32_t first, uint32_t count, uint32_t P,
+                                 const uint8_t* pkind, int cp_zero, float* out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint64_t)count * P) return;
+    const uint32_t j = (uint32_t)(idx / P), i = (uint32_t)(idx % P);
+    const uint32_t nkeys = 2u * (s_total + 1u), row = first + j + 1u;
+    const uint32_t ka = random_bits_at(0u, seed, nkeys, 2u * row), kb = random_bits_at(0u, seed, nkeys, 2u * row + 1u);
+    const uint32_t s0 = random_bits_at(ka, kb, 4u, 2u), s1 = random_bits_at(ka, kb, 4u, 3u);
+    const uint32_t bits = random_bits_at(s0, s1, P, i);
+    float f = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+    f = __fmul_rn(f, 6.2831855f);
+    f = fmaxf(0.f, f);
+    if (cp_zero && pkind[i]) f = 0.f;
+    out[idx] = f;
+}
+
+}  // namespace cpf

@@ -1,0 +1,372 @@
+// cpflow_amd host side of the C ABI (include/cpflow_amd.h): plan construction
+// (gate program, embedded target, penalty table, Adam bias-correction table),
+// kernel variant selection and launches.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/cpflow_amd.h"
+#include "cpf_device.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CPF_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct cpf_plan {
+    int device = 0;
+    int n = 0, K = 0, n_rot = 0, nb = 0, P = 0, G = 0, T = 0, NQ = 0;
+    int entangler = 0;
+    std::vector<uint8_t> h_pkind;
+    std::vector<int4> h_prog;
+    DevBuf d_prog, d_target, d_pkind, d_bias;
+    cpf::KArgs base{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int num_cu = 256;
+    ~cpf_plan() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+namespace {
+
+// Penalty table: the reference builds slopes / intercepts / break points from Python floats
+// (double) and they meet the float32 angle as float32 scalars (penalty.py:14-15, 44-71).
+void build_pieces(const cpf_penalty& po, cpf::Piece pc[10]) {
+    const double pi = 3.141592653589793, xm = po.xmax, ym = po.ymax, p0 = po.plato_0, p1 = po.plato_1, p2 = po.plato_2;
+    const double X[11] = {0, p0, xm - p2, xm + p2, pi - p1, pi + p1, pi + xm - p2, pi + xm + p2, 2 * pi - p0, 2 * pi, 3 * pi};
+    const double Y[11] = {0, 0, ym, ym, 1, 1, ym, ym, 0, 0, 0};
+    for (int i = 0; i < 9; i++) {
+        const double x0 = X[i], y0 = Y[i], x1 = X[i + 1], y1 = Y[i + 1];
+        pc[i].lo = (float)x0;
+        pc[i].hi = (float)x1;
+        pc[i].slope = (float)((y1 - y0) / (x1 - x0));
+        pc[i].icpt = (float)((x0 * y1 - x1 * y0) / (x0 - x1));
+    }
+    pc[9].lo = (float)X[9]; pc[9].hi = (float)X[10]; pc[9].slope = 0.f; pc[9].icpt = 1.f;
+}
+
+int validate(const cpf_problem* pb) {
+    if (!pb) return fail(-1, "problem is NULL");
+    if (pb->n_qubits < CPF_MIN_QUBITS || pb->n_qubits > CPF_MAX_QUBITS)
+        return fail(-2, "n_qubits=%d outside [%d, %d]", pb->n_qubits, CPF_MIN_QUBITS, CPF_MAX_QUBITS);
+    if (pb->num_blocks < 0) return fail(-3, "num_blocks=%d < 0", pb->num_blocks);
+    if (pb->num_blocks > 0 && !pb->placements) return fail(-3, "placements is NULL");
+    if (pb->n_rot < 0 || pb->n_rot > 8 || (pb->n_rot > 0 && !pb->rot_axes)) return fail(-4, "bad rotation_gates");
+    for (int i = 0; i < pb->n_rot; i++)
+        if (pb->rot_axes[i] != 'x' && pb->rot_axes[i] != 'y' && pb->rot_axes[i] != 'z')
+            return fail(-4, "rotation gate '%c' not in {x,y,z}", pb->rot_axes[i]);
+    if (pb->entangler != CPF_ENTANGLER_CP && pb->entangler != CPF_ENTANGLER_CZ)
+        return fail(-5, "entangler %d not supported on device (cp, cz)", pb->entangler);
+    if (pb->loss_kind != CPF_LOSS_HST) return fail(-6, "loss_kind %d not supported", pb->loss_kind);
+    if (!pb->target) return fail(-7, "target is NULL");
+    for (int b = 0; b < pb->num_blocks; b++) {
+        const int p0 = pb->placements[2 * b], p1 = pb->placements[2 * b + 1];
+        if (p0 < 0 || p1 < 0 || p0 >= pb->n_qubits || p1 >= pb->n_qubits || p0 == p1)
+            return fail(-3, "placement %d = [%d, %d] invalid for %d qubits", b, p0, p1, pb->n_qubits);
+    }
+    if (pb->num_iterations < 0) return fail(-8, "num_iterations < 0");
+    if (pb->penalty.kind != CPF_PENALTY_LINEAR && pb->penalty.kind != CPF_PENALTY_L1) return fail(-9, "penalty kind");
+    return 0;
+}
+
+template <int NQ, int LW>
+int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+    using L = cpf::Lay<NQ, LW>;
+    const size_t lds = cpf::lds_floats(a.P, L::WPS) * sizeof(float);
+    if (lds > 160 * 1024) return fail(-20, "P=%d needs %zu B of LDS (> 160 KiB)", a.P, lds);
+    if (lds > 64 * 1024)
+        CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_template<NQ, LW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((cpf::k_cp_template<NQ, LW>), dim3((unsigned)S), dim3(L::THREADS), lds, stream, a);
+    CPF_HIP(hipGetLastError());
+    return 0;
+}
+
+// Variant choice: one workgroup per sample; more waves per sample when there are too few
+// samples to fill 256 CUs x 4 SIMDs and the matrix is large enough to split by columns.
+int launch(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+    if (S <= 0) return 0;
+    if (S > 0x7fffffffLL) return fail(-21, "num_samples too large");
+    const int64_t simds = (int64_t)plan->num_cu * 4;
+    switch (plan->NQ) {
+        case 3: return launch_variant<3, 0>(a, S, stream);
+        case 4: return (S >= 2 * simds) ? launch_variant<4, 0>(a, S, stream) : launch_variant<4, 2>(a, S, stream);
+        case 5: return (S >= 4 * simds) ? launch_variant<5, 0>(a, S, stream) : launch_variant<5, 2>(a, S, stream);
+        case 6: return launch_variant<6, 2>(a, S, stream);
+        default: return fail(-2, "unsupported kernel width %d", plan->NQ);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cpf_version(void) { return CPF_VERSION; }
+
+int32_t cpf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* cpf_last_error(void) { return g_err; }
+
+int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_plan) {
+    if (!out_plan) return fail(-1, "out_plan is NULL");
+    *out_plan = nullptr;
+    if (int rc = validate(pb)) return rc;
+    CPF_HIP(hipSetDevice(device));
+    cpf_plan* pl = new cpf_plan();
+    pl->device = device;
+    pl->n = pb->n_qubits; pl->K = pb->num_blocks; pl->n_rot = pb->n_rot; pl->entangler = pb->entangler;
+    pl->nb = 2 * pb->n_rot + (pb->entangler == CPF_ENTANGLER_CP ? 1 : 0);
+    pl->P = 3 * pl->n + pl->nb * pl->K;
+    pl->T = pb->num_iterations;
+    pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
+    const int n = pl->n, NQ = pl->NQ, N = 1 << n, D = 1 << NQ, P = pl->P;
+
+    // ---- gate program (main.py:106-146): surface Rz Rx Rz per qubit, then per block
+    //      entangler followed by R_g(up) R_g(down) for each letter g (main.py:69-82)
+    pl->h_pkind.assign(P, 0);
+    auto& prog = pl->h_prog;
+    for (int q = 0; q < n; q++) {
+        prog.push_back(make_int4(cpf::OP_RZ, q, 0, 3 * q + 0));
+        prog.push_back(make_int4(cpf::OP_RX, q, 0, 3 * q + 1));
+        prog.push_back(make_int4(cpf::OP_RZ, q, 0, 3 * q + 2));
+    }
+    for (int b = 0; b < pl->K; b++) {
+        const int up = pb->placements[2 * b], dn = pb->placements[2 * b + 1], base = 3 * n + pl->nb * b;
+        const int lo = up < dn ? up : dn, hi = up < dn ? dn : up;
+        if (pb->entangler == CPF_ENTANGLER_CP) {
+            prog.push_back(make_int4(cpf::OP_CP, lo, hi, base + pl->nb - 1));
+            pl->h_pkind[base + pl->nb - 1] = 1;
+        } else {
+            prog.push_back(make_int4(cpf::OP_CZ, lo, hi, 0));
+        }
+        for (int i = 0; i < pb->n_rot; i++) {
+            const int kind = pb->rot_axes[i] == 'x' ? cpf::OP_RX : (pb->rot_axes[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
+            prog.push_back(make_int4(kind, up, 0, base + 2 * i));
+            prog.push_back(make_int4(kind, dn, 0, base + 2 * i + 1));
+        }
+    }
+    pl->G = (int)prog.size();
+
+    // ---- target, used as complex64, embedded as V (x) I when the kernel is wider than the problem
+    std::vector<float2> tgt((size_t)D * D, make_float2(0.f, 0.f));
+    const int d = NQ - n;
+    for (int r = 0; r < N; r++)
+        for (int c = 0; c < N; c++)
+            for (int x = 0; x < (1 << d); x++)
+                tgt[(size_t)((r << d) | x) * D + ((c << d) | x)] =
+                    make_float2((float)pb->target[2 * ((size_t)r * N + c)], (float)pb->target[2 * ((size_t)r * N + c) + 1]);
+
+    // ---- Adam bias corrections 1 - b^t in float32 (optax 0.1.1 bias_correction)
+    std::vector<float2> bias((size_t)(pl->T > 0 ? pl->T : 1));
+    const float b1f = (float)pb->b1, b2f = (float)pb->b2;
+    for (int t = 1; t <= pl->T; t++)
+        bias[t - 1] = make_float2(1.0f - powf(b1f, (float)t), 1.0f - powf(b2f, (float)t));
+
+    hipError_t e = hipSuccess;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = b.alloc(bytes);
+        if (e == hipSuccess && bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    up(pl->d_prog, prog.data(), prog.size() * sizeof(int4));
+    up(pl->d_target, tgt.data(), tgt.size() * sizeof(float2));
+    up(pl->d_pkind, pl->h_pkind.data(), (size_t)P);
+    up(pl->d_bias, bias.data(), bias.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete pl;
+        return fail((int)e, "plan upload failed: %s", hipGetErrorString(e));
+    }
+    pl->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    cpf::KArgs& a = pl->base;
+    a.prog = pl->d_prog.as<int4>(); a.G = pl->G; a.P = P; a.T = pl->T; a.mode = cpf::MODE_OPTIMIZE;
+    a.n_actual = n;
+    a.target = pl->d_target.as<float2>();
+    a.pkind = pl->d_pkind.as<uint8_t>();
+    a.bias = pl->d_bias.as<float2>();
+    build_pieces(pb->penalty, a.pc);
+    a.pen_kind = pb->penalty.kind;
+    a.use_reg = (pb->use_reg && pb->entangler == CPF_ENTANGLER_CP) ? 1 : 0;
+    a.r = (float)pb->r;
+    a.lr = (float)pb->lr; a.b1 = b1f; a.b2 = b2f; a.eps = (float)pb->eps;
+    a.omb1 = (float)(1.0 - pb->b1); a.omb2 = (float)(1.0 - pb->b2);
+    a.thr_cp = (float)pb->threshold_cp; a.entry_loss = (float)pb->entry_loss;
+    a.inv_dim2 = 1.0f / ((float)D * (float)D);
+    *out_plan = pl;
+    return 0;
+}
+
+int32_t cpf_plan_destroy(cpf_plan* plan) {
+    if (!plan) return 0;
+    (void)hipSetDevice(plan->device);
+    delete plan;
+    return 0;
+}
+
+int32_t cpf_plan_num_params(const cpf_plan* plan) { return plan ? plan->P : fail(-1, "plan is NULL"); }
+int32_t cpf_plan_num_gates(const cpf_plan* plan) { return plan ? plan->G : fail(-1, "plan is NULL"); }
+
+int32_t cpf_plan_cp_mask(const cpf_plan* plan, uint8_t* out_mask) {
+    if (!plan || !out_mask) return fail(-1, "NULL argument");
+    memcpy(out_mask, plan->h_pkind.data(), (size_t)plan->P);
+    return 0;
+}
+
+double cpf_plan_flops_per_sample_step(const cpf_plan* plan) {
+    if (!plan) return 0.0;
+    // F = 3 N^2 (32 K + 16 n) + 20 P
+    const double N = (double)(1 << plan->n);
+    return 3.0 * N * N * (32.0 * plan->K + 16.0 * plan->n) + 20.0 * plan->P;
+}
+
+int32_t cpf_initial_angles_device(const cpf_plan* plan, uint32_t seed, int64_t num_samples_total, int64_t first,
+                                  int64_t count, int32_t cp_zero, float* d_angles, void* stream) {
+    if (!plan) return fail(-1, "plan is NULL");
+    if (count == 0) return 0;
+    if (!d_angles) return fail(-1, "d_angles is NULL");
+    if (first < 0 || count < 0 || first + count > num_samples_total || num_samples_total >= 0x7fffffffLL)
+        return fail(-10, "bad sample range first=%lld count=%lld total=%lld", (long long)first, (long long)count,
+                    (long long)num_samples_total);
+    CPF_HIP(hipSetDevice(plan->device));
+    const uint64_t total = (uint64_t)count * plan->P;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(cpf::k_initial_angles, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed,
+                       (uint32_t)num_samples_total, (uint32_t)first, (uint32_t)count, (uint32_t)plan->P,
+                       plan->d_pkind.as<uint8_t>(), cp_zero, d_angles);
+    CPF_HIP(hipGetLastError());
+    return 0;
+}
+
+int32_t cpf_optimize_device(const cpf_plan* plan_c, int64_t S, const float* d_init, const uint8_t* d_frozen,
+                            float* d_params, float* d_regloss, float* d_loss, float* d_reg, int32_t* d_cz,
+                            uint8_t* d_pass, float* d_hist_params, float* d_hist_loss, void* stream) {
+    cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
+    if (!plan) return fail(-1, "plan is NULL");
+    if (S == 0) return 0;
+    if (!d_init || !d_params || !d_regloss || !d_loss || !d_reg || !d_cz || !d_pass) return fail(-1, "NULL buffer");
+    CPF_HIP(hipSetDevice(plan->device));
+    cpf::KArgs a = plan->base;
+    a.mode = cpf::MODE_OPTIMIZE;
+    a.init = d_init; a.frozen = d_frozen;
+    a.out_params = d_params; a.out_regloss = d_regloss; a.out_loss = d_loss; a.out_reg = d_reg;
+    a.out_cz = d_cz; a.out_pass = d_pass;
+    a.hist_params = d_hist_params; a.hist_loss = d_hist_loss;
+    CPF_HIP(hipEventRecord(plan->ev0, (hipStream_t)stream));
+    if (int rc = launch(plan, a, S, (hipStream_t)stream)) return rc;
+    CPF_HIP(hipEventRecord(plan->ev1, (hipStream_t)stream));
+    plan->timed = true;
+    return 0;
+}
+
+int32_t cpf_plan_last_kernel_ms(cpf_plan* plan, float* out_ms) {
+    if (!plan || !out_ms) return fail(-1, "NULL argument");
+    if (!plan->timed) return fail(-11, "no optimize launch recorded on this plan");
+    CPF_HIP(hipEventSynchronize(plan->ev1));
+    CPF_HIP(hipEventElapsedTime(out_ms, plan->ev0, plan->ev1));
+    return 0;
+}
+
+int32_t cpf_loss_grad_device(const cpf_plan* plan, int64_t S, const float* d_theta, float* d_loss, float* d_reg,
+                             float* d_regloss, float* d_grad, void* stream) {
+    if (!plan) return fail(-1, "plan is NULL");
+    if (S == 0) return 0;
+    if (!d_theta || !d_loss || !d_reg || !d_regloss) return fail(-1, "NULL buffer");
+    CPF_HIP(hipSetDevice(plan->device));
+    cpf::KArgs a = plan->base;
+    a.mode = cpf::MODE_LOSS_GRAD;
+    a.init = d_theta; a.frozen = nullptr;
+    a.out_loss = d_loss; a.out_reg = d_reg; a.out_regloss = d_regloss; a.out_grad = d_grad;
+    return launch(plan, a, S, (hipStream_t)stream);
+}
+
+int32_t cpf_unitary_device(const cpf_plan* plan, int64_t S, const float* d_theta, float* d_unitary, void* stream) {
+    if (!plan) return fail(-1, "plan is NULL");
+    if (S == 0) return 0;
+    if (!d_theta || !d_unitary) return fail(-1, "NULL buffer");
+    CPF_HIP(hipSetDevice(plan->device));
+    cpf::KArgs a = plan->base;
+    a.mode = cpf::MODE_UNITARY;
+    a.init = d_theta; a.frozen = nullptr;
+    a.out_U = reinterpret_cast<float2*>(d_unitary);
+    return launch(plan, a, S, (hipStream_t)stream);
+}
+
+int32_t cpf_run_static(const cpf_problem* problem, int32_t device, uint32_t seed, int64_t num_samples_total,
+                       int64_t first, int64_t S, int32_t cp_zero, const float* init, const uint8_t* frozen,
+                       cpf_result* out) {
+    if (!out || !out->params || !out->regloss || !out->loss || !out->reg || !out->cz || !out->pass)
+        return fail(-1, "result buffers must be allocated by the caller");
+    if (S < 0) return fail(-10, "num_samples < 0");
+    cpf_plan* plan = nullptr;
+    if (int rc = cpf_plan_create(problem, device, &plan)) return rc;
+    int rc = 0;
+    {
+        const size_t P = (size_t)plan->P, n = (size_t)S;
+        DevBuf d_init, d_frozen, d_params, d_regloss, d_loss, d_reg, d_cz, d_pass;
+        hipError_t e = hipSuccess;
+        auto al = [&](DevBuf& b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
+        al(d_init, n * P * 4); al(d_params, n * 2 * P * 4); al(d_regloss, n * 8); al(d_loss, n * 8); al(d_reg, n * 8);
+        al(d_cz, n * 4); al(d_pass, n);
+        if (frozen) al(d_frozen, n * P);
+        if (e == hipSuccess && init) e = hipMemcpy(d_init.p, init, n * P * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && frozen) e = hipMemcpy(d_frozen.p, frozen, n * P, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail((int)e, "device allocation / upload failed: %s", hipGetErrorString(e));
+        if (!rc && !init)
+            rc = cpf_initial_angles_device(plan, seed, num_samples_total, first, S, cp_zero, d_init.as<float>(), nullptr);
+        if (!rc)
+            rc = cpf_optimize_device(plan, S, d_init.as<float>(), frozen ? d_frozen.as<uint8_t>() : nullptr,
+                                     d_params.as<float>(), d_regloss.as<float>(), d_loss.as<float>(), d_reg.as<float>(),
+                                     d_cz.as<int32_t>(), d_pass.as<uint8_t>(), nullptr, nullptr, nullptr);
+        if (!rc) {
+            e = hipDeviceSynchronize();
+            auto dn = [&](void* dst, const DevBuf& b, size_t bytes) {
+                if (e == hipSuccess && bytes) e = hipMemcpy(dst, b.p, bytes, hipMemcpyDeviceToHost);
+            };
+            dn(out->params, d_params, n * 2 * P * 4); dn(out->regloss, d_regloss, n * 8); dn(out->loss, d_loss, n * 8);
+            dn(out->reg, d_reg, n * 8); dn(out->cz, d_cz, n * 4); dn(out->pass, d_pass, n);
+            if (e != hipSuccess) rc = fail((int)e, "kernel / download failed: %s", hipGetErrorString(e));
+        }
+    }
+    cpf_plan_destroy(plan);
+    return rc;
+}
+
+}  // extern "C"
