@@ -1,0 +1,32 @@
+"""Build the HIP library in-tree:  python -m cpflow_amd.build
+
+hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels to the
+GPU box with the source snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
+DEPS = [SRC, os.path.join(HERE, 'csrc', 'cpf_device.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
+OUT = os.path.join(HERE, 'libcpflow_amd.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function']
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [HIPCC] + FLAGS + ['-o', OUT, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

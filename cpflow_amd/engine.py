@@ -37,7 +37,7 @@ class TemplateEngine:
     def __init__(self, layer, num_cp_gates, target_unitary, rotation_gates='xyz', r=0.00055,
                  entangler='cp', use_reg=True, penalty='linear', xmax=math.pi / 2, ymax=2.0,
                  plato_0=0.05, plato_1=0.05, plato_2=0.05, learning_rate=0.1, num_gd_iterations=2000,
-                 threshold_cp=0.2, entry_loss=1e-3, num_qubits=None, device=None):
+                 threshold_cp=0.2, entry_loss=1e-3, num_qubits=None, device=None, placements=None):
         if not torch.cuda.is_available():
             raise _ffi.CpfError('cpflow_amd needs a ROCm GPU: torch.cuda.is_available() is False '
                                 '(there is no CPU fallback).')
@@ -52,7 +52,11 @@ class TemplateEngine:
         target = np.ascontiguousarray(np.asarray(target_unitary, dtype=np.complex128))
         assert target.shape == (N, N), 'Number of qubits in target unitary and layer do not match.'
         self._target = target
-        self._placements = placements_for(self.layer, self.num_cp_gates)
+        if placements is not None:      # explicit block placements (Ansatz); otherwise the layer is cycled
+            self._placements = np.ascontiguousarray(np.asarray(placements, dtype=np.int32).reshape(-1, 2))
+            assert len(self._placements) == self.num_cp_gates
+        else:
+            self._placements = placements_for(self.layer, self.num_cp_gates)
         self._rot = self.rotation_gates.encode()
         if entangler not in _ffi.ENTANGLER:
             raise TypeError(f"Gate '{entangler}' not implemented.")
@@ -78,6 +82,7 @@ class TemplateEngine:
         _ffi.check(self._lib.cpf_plan_cp_mask(self._plan, mask.ctypes.data))
         self.cp_mask = mask
         self.flops_per_sample_step = float(self._lib.cpf_plan_flops_per_sample_step(self._plan))
+        self.event_log = None      # set to [] to collect (start, end) stream events around every optimize launch
 
     def close(self):
         if getattr(self, '_plan', None):
@@ -133,15 +138,27 @@ class TemplateEngine:
                    reg=self._empty((S, 2)), cz=self._empty((S,), torch.int32), passed=self._empty((S,), torch.uint8))
         hp = self._empty((S, T, P)) if keep_history else None
         hl = self._empty((S, T)) if keep_history else None
+        if self.event_log is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self.device))
         _ffi.check(self._lib.cpf_optimize_device(
             self._plan, S, self._ptr(init), self._ptr(fz), self._ptr(out['params']), self._ptr(out['regloss']),
             self._ptr(out['loss']), self._ptr(out['reg']), self._ptr(out['cz']), self._ptr(out['passed']),
             self._ptr(hp), self._ptr(hl), self._stream()))
+        if self.event_log is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self.event_log.append(ev)
         out['passed'] = out['passed'].bool()
         if keep_history:
             out['history_params'], out['history_regloss'] = hp, hl
         self._keepalive = (init, fz)
         return out
+
+    def mean_kernel_ms(self):
+        """Average duration of the optimize launches logged in event_log (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        times = [a.elapsed_time(b) for a, b in self.event_log]
+        return sum(times) / len(times), times
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -1,0 +1,56 @@
+"""CPU: the N>1 path (sample sharding + the one all-gather) with gloo, world_size 2 and 3."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpflow_amd import distributed
+
+
+def test_shard_ranges_partition_all_samples():
+    for S in (0, 1, 7, 10, 1024, 4097):
+        for R in (1, 2, 3, 8):
+            seen = []
+            for r in range(R):
+                first, count = distributed.shard_range(S, r, R)
+                assert 0 <= count <= distributed.shard_capacity(S, R)
+                seen += list(range(first, first + count))
+            assert seen == list(range(S))
+
+
+def _worker(rank, size, port, S, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        first, count = distributed.shard_range(S, rank, size)
+        g = torch.Generator().manual_seed(1234)
+        full = {'params': torch.rand(S, 2, 5, generator=g), 'regloss': torch.rand(S, 2, generator=g),
+                'cz': torch.randint(0, 30, (S,), generator=g, dtype=torch.int32),
+                'passed': torch.rand(S, generator=g) > 0.5}
+        local = {k: v[first:first + count] for k, v in full.items()}
+        out = distributed.gather_samples(local, S)
+        ok = all(out[k].dtype == full[k].dtype and torch.equal(out[k], full[k]) for k in full)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('size,S', [(2, 10), (2, 7), (3, 8)])
+def test_gather_equals_single_rank(size, S):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, size, port, S, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(size)]

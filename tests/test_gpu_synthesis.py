@@ -1,0 +1,163 @@
+"""GPU parity at the level the reference's callers see: golden end-of-run statistics, the
+Synthesize front end, rank-independence of sharding, determinism, BASELINE-size properties."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from oracle import Oracle  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+CCZ = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(np.complex128)
+TOFF3 = np.eye(8)[[0, 1, 2, 3, 4, 5, 7, 6]].astype(np.complex128)
+
+
+def _engine(*a, **kw):
+    from cpflow_amd.engine import TemplateEngine
+    return TemplateEngine(*a, **kw)
+
+
+def _np(d):
+    return {k: v.cpu().numpy() for k, v in d.items() if v is not None}
+
+
+@pytest.mark.parametrize('name,min_same', [('raw_toff3_chain_t49', 0.95), ('raw_toff3_chain_t19', 0.95),
+                                           ('raw_toff4_star_t14', 0.75)])
+def test_T3_golden_end_of_run(name, min_same):
+    """Full 2000-iteration runs from the reference's seeds reproduce its stored results:
+    same pass/fail set, same CZ counts except boundary samples, best regloss statistically equal.
+    On the 4-qubit fixture 2000 Adam steps at lr=0.1 are chaotic enough that even the float64
+    oracle reproduces only 55/63 of the reference's per-sample CZ counts (float32 oracle 53/63),
+    so there the bar is 75 % per-sample agreement plus agreement of the adaptive score."""
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    S = int(g['num_samples'])
+    eng = _engine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
+    init = eng.initial_angles(int(g['seed']), S)
+    out = _np(eng.optimize(init))
+    idx = g['sample_index']
+    assert (out['params'][idx, 0].view(np.uint32) == g['params'][:, 0].view(np.uint32)).all()   # T0
+    passed = set(np.flatnonzero(out['passed']))
+    # a sample whose final loss sits within 2e-4 of entry_loss may land on either side
+    border = set(np.flatnonzero(np.abs(np.take_along_axis(out['loss'], out['regloss'].argmin(1)[:, None], 1)[:, 0] - 1e-3) < 2e-4))
+    assert (passed ^ set(idx)) <= border
+    both = [k for k, j in enumerate(idx) if j in passed]
+    same = out['cz'][idx[both]] == g['cz'][both]
+    assert same.mean() >= min_same, f'{(~same).sum()} CZ counts differ'
+    score = -np.log2((2.0 ** -out['cz'][out['passed']].astype(np.float32)).sum() / S)
+    assert abs(score - float(g['score'])) < 0.35
+    for k in (np.flatnonzero(~same) if min_same >= 0.95 else []):   # 3q: every mismatch is a threshold-boundary sample
+        j = idx[both][k]
+        th = out['params'][j, 1][eng.cp_mask == 1] % np.float32(2 * np.pi)
+        dist = np.minimum.reduce([np.abs(th - 0.2), np.abs(th - (np.pi - 0.2)), np.abs(th - (np.pi + 0.2)),
+                                  np.abs(th - (2 * np.pi - 0.2))])
+        assert dist.min() < 0.05
+    d = np.abs(out['regloss'][idx[both], 1] - g['regloss'][both, 1])
+    assert np.median(d) < (2e-5 if min_same >= 0.95 else 1e-4) and d.max() < 2e-3
+    # T1 at the reference's own best angles
+    at = _np(eng.loss_and_grad(g['params'][:, 1, :]))
+    assert np.abs(at['loss'] - g['loss'][:, 1]).max() < 1.5e-5
+    assert np.abs(at['reg'] - g['reg'][:, 1]).max() < 1e-7
+
+
+def test_G6_decompositions_rebuild_target():
+    for name in ('dec_refine_test', 'dec_toff3_chain', 'dec_toff4_star'):
+        g = np.load(os.path.join(GOLD, name + '.npz'))
+        for i in range(len(g['angles'])):
+            K, rot = int(g['num_cp_gates'][i]), str(g['rotation_gates'][i])
+            eng = _engine(g['layer'], K, g['target'], rot, use_reg=False)
+            res = eng.loss_and_grad(g['angles'][i, :eng.num_angles], with_grad=False)
+            assert float(res['loss'][0]) < 3e-6
+            eng.close()
+
+
+def test_sharded_runs_equal_single_run_bitwise():
+    """Rank-independence: running the sample blocks of 1, 2 or 3 'ranks' separately gives
+    bit-identical rows; two identical launches are bit-identical too."""
+    eng = _engine([[0, 1], [0, 2], [1, 2]], 16, TOFF3, 'xyz', num_gd_iterations=300)
+    S = 50
+    full = _np(eng.optimize(eng.initial_angles(7, S)))
+    again = _np(eng.optimize(eng.initial_angles(7, S)))
+    for k in full:
+        assert (full[k] == again[k]).all()
+    from cpflow_amd.distributed import shard_range
+    for R in (2, 3):
+        parts = []
+        for r in range(R):
+            first, count = shard_range(S, r, R)
+            parts.append(_np(eng.optimize(eng.initial_angles(7, S, first, count))))
+        for k in full:
+            assert (np.concatenate([p[k] for p in parts]) == full[k]).all()
+
+
+def test_static_front_end_config1(capsys):
+    """BASELINE config 1 through the reference-shaped API: CCZ, chain, 12 CP gates, 10 samples, seed 0."""
+    from cpflow_amd import StaticOptions, Synthesize
+    layer = [[0, 1], [1, 2]]
+    opts = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10, num_samples=10)
+    syn = Synthesize(layer, target_unitary=CCZ, label='ccz_chain')
+    raw = syn._generate_raw(opts)
+    assert len(raw) == 10 and set(raw[0]) == {'params', 'loss', 'reg', 'regloss'}
+    assert raw[0]['params'].shape == (2, 93) and raw[0]['regloss'].shape == (2,)
+    ref = Oracle(layer, 12, CCZ, 'xyz').run(oracle.prng.initial_angles(0, 10, 93), np.float32)
+    assert (raw.passed == ref['passed']).all()
+    assert (raw.cz[raw.passed] == ref['cz'][ref['passed']]).mean() >= 0.8
+    sel = syn._evaluate_raw(raw, opts)
+    assert [c for c, _ in sel] == sorted(c for c, _ in sel) and len(sel) == int(raw.passed.sum())
+    results = syn.static(opts, save_results=False)
+    decs = results.decompositions
+    assert len(decs) >= 5                       # restatement: 7 prospective
+    for d in decs:
+        assert d.loss < 1e-5 and d.cz_count <= 10 and d.type == 'Approximate'
+        assert d.circuit.count_ops().get('cp', 0) == 0 and d.cz_depth <= d.cz_count
+        assert repr(d).startswith('< ccz_chain| Approximate | loss: ')
+    assert min(d.cz_count for d in decs) == 8   # README.md:37-41: an 8-CZ decomposition exists
+    text = capsys.readouterr().out
+    assert 'Computing raw results...' in text and 'successful. cz counts are:' in text
+
+
+def test_tutorial_known_answer_K1():
+    """Tutorial cell 27: Toffoli, chain, K=14, r=0.00055, 4 samples, seed 0 -> 4 successful,
+    cz counts [8, 9, 14, 15]; one sample sits 0.02 inside the 0.2 window, so its 15 may read 14."""
+    from cpflow_amd import StaticOptions, Synthesize
+    opts = StaticOptions(num_cp_gates=14, accepted_num_cz_gates=20, num_samples=4)
+    res = Synthesize([[0, 1], [1, 2]], target_unitary=TOFF3, label='toff3').static(opts, save_results=False)
+    counts = sorted(d.cz_count for d in res.decompositions)
+    assert len(counts) == 4 and counts[:2] == [8, 9] and counts[2] == 14 and counts[3] in (14, 15)
+
+
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg4'])
+def test_full_size_properties(cfg):
+    """BASELINE-size runs (config 2: 3q CCZ S=1024; config 4: 4q QFT S=2048) checked through
+    size-independent properties of the outputs."""
+    if cfg == 'cfg2':
+        layer, K, target, S = [[0, 1], [1, 2]], 12, CCZ, 1024
+    else:
+        w = np.exp(2j * np.pi / 16)
+        target = np.array([[w ** (j * k) for k in range(16)] for j in range(16)]) / 4
+        layer, K, S = [[0, 1], [1, 2], [2, 3]], 24, 2048
+    eng = _engine(layer, K, target, 'xyz')
+    init = eng.initial_angles(0, S)
+    out = _np(eng.optimize(init))
+    assert (out['params'][:, 0] == init.cpu().numpy()).all()
+    assert (out['regloss'][:, 1] <= out['regloss'][:, 0]).all()
+    assert (out['loss'] == out['regloss'] - out['reg']).all()
+    assert (out['reg'] >= 0).all() and np.isfinite(out['params']).all()
+    bi = out['regloss'].argmin(1)
+    lbest = np.take_along_axis(out['loss'], bi[:, None], 1)[:, 0]
+    assert (out['passed'] == (lbest <= np.float32(1e-3))).all()
+    # re-evaluating the stored best angles reproduces the stored best regloss (same kernel arithmetic)
+    re = _np(eng.loss_and_grad(out['params'][:, 1], with_grad=False))
+    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < 1e-6
+    # CZ count recomputed on the host from the best angles
+    cp = out['params'][np.arange(S), bi][:, eng.cp_mask == 1] % np.float32(2 * np.pi)
+    v = np.full(cp.shape, 2)
+    v[cp < 0.2] = 0
+    v[np.abs(cp - np.float32(2 * np.pi)) < 0.2] = 0
+    v[np.abs(cp - np.float32(np.pi)) < 0.2] = 1
+    assert (v.sum(1) == out['cz']).all()
+    if cfg == 'cfg2':
+        assert out['passed'].mean() > 0.5
+        assert out['cz'][out['passed']].min() <= 8

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the product package (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cpflow_amd
+from cpflow_amd import AdaptiveOptions, StaticOptions, chain_layer, connected_layer, fill_layers
+from cpflow_amd.circuit import Circuit, zxz_angles
+from cpflow_amd.engine import placements_for
+from cpflow_amd.synthesis import HSTLoss, project_cp_angles, theoretical_lower_bound
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The .so loads and exports exactly the functions include/cpflow_amd.h declares."""
+    from cpflow_amd import _ffi
+    header = open(os.path.join(ROOT, 'include', 'cpflow_amd.h')).read()
+    declared = set(re.findall(r'\b(cpf_[a-z_]+)\s*\(', header))
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    lib = _ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.cpf_version() == 100
+    assert lib.cpf_device_count() >= 0
+
+
+def test_abi_argument_validation_without_gpu():
+    from cpflow_amd import _ffi
+    lib = _ffi.lib()
+    handle = ctypes.c_void_p()
+    pb = _ffi.Problem()
+    pb.n_qubits = 9
+    rc = lib.cpf_plan_create(ctypes.byref(pb), 0, ctypes.byref(handle))
+    assert rc < 0 and b'n_qubits' in lib.cpf_last_error()
+    assert lib.cpf_plan_num_params(None) < 0
+
+
+def test_options_mirror_reference_defaults():
+    with pytest.raises(TypeError, match="num_cp_gates"):
+        StaticOptions(accepted_num_cz_gates=3)
+    with pytest.raises(TypeError, match="accepted_num_cz_gates"):
+        StaticOptions(num_cp_gates=3)
+    with pytest.raises(TypeError, match="min_num_cp_gates"):
+        AdaptiveOptions(max_num_cp_gates=3)
+    o = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10)
+    assert (o.num_samples, o.method, o.learning_rate, o.num_gd_iterations, o.cp_distribution) == (100, 'adam', 0.1, 2000, 'uniform')
+    assert (o.entry_loss, o.target_loss, o.threshold_cp, o.r) == (1e-3, 1e-6, 0.2, 0.00055)
+    assert (o.learning_rate_at_verification, o.num_gd_iterations_at_verification, o.random_seed, o.rotation_gates) == (0.01, 5000, 0, 'xyz')
+    a = AdaptiveOptions(min_num_cp_gates=4, max_num_cp_gates=9, num_samples=7, rotation_gates='xz')
+    s = a.get_static(6, 0.001)
+    assert (s.num_cp_gates, s.r, s.accepted_num_cz_gates, s.num_samples, s.rotation_gates) == (6, 0.001, None, 7, 'xz')
+    assert repr(o).startswith('StaticOptions(num_samples=100, method=')
+
+
+def test_topology_and_placements():
+    assert connected_layer(3) == [[0, 1], [0, 2], [1, 2]] and chain_layer(4) == [[0, 1], [1, 2], [2, 3]]
+    f = fill_layers([[0, 1], [1, 2]], 5)
+    assert f == {'layers': [[[0, 1], [1, 2]], 2], 'free': [[0, 1]]}
+    assert placements_for([[0, 1], [1, 2]], 5).tolist() == [[0, 1], [1, 2], [0, 1], [1, 2], [0, 1]]
+    assert theoretical_lower_bound(3) == 14 and theoretical_lower_bound(4) == 61
+
+
+def test_circuit_ir():
+    rng = np.random.default_rng(0)
+    qc = Circuit(3)
+    for q in range(3):
+        qc.rz(rng.uniform(0, 6), q).rx(rng.uniform(0, 6), q).ry(rng.uniform(0, 6), q)
+    qc.cp(1.234, 2, 0).rx(0.3, 0).cp(np.pi, 0, 1).cp(1e-9, 1, 2).rz(0.7, 2).cz(1, 2)
+    u = qc.unitary()
+    assert np.abs(u.conj().T @ u - np.eye(8)).max() < 1e-12
+    cz = qc.cp_to_cz(cp_threshold=1e-6)
+    assert cz.count_ops().get('cp', 0) == 0 and cz.count_ops()['cz'] == 2 + 1 + 0 + 1
+    loss = HSTLoss(u)
+    assert loss(cz.unitary()) < 1e-12                       # exact up to a global phase
+    z = cz.to_zxz()
+    assert loss(z.unitary()) < 1e-12 and set(z.count_ops()) <= {'rz', 'rx', 'cz'}
+    assert z.count_ops()['cz'] == 4 and z.depth(['cz']) == cz.depth(['cz'])
+    # qubit 0 is the most significant bit
+    x0 = Circuit(2).rx(np.pi, 0).unitary()
+    assert abs(abs(x0[2, 0]) - 1) < 1e-12
+    for _ in range(20):
+        m = np.linalg.qr(rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)))[0]
+        z1, x, z2 = zxz_angles(m)
+        r = Circuit(1).rz(z1, 0).rx(x, 0).rz(z2, 0).unitary()
+        assert abs(abs(np.trace(r.conj().T @ m)) - 2) < 1e-9
+    assert 'q0:' in qc.draw() and 'OPENQASM' in qc.qasm()
+    d = Circuit(3).cz(0, 1).cz(1, 2).cz(0, 1).rx(1, 0).cz(0, 2)
+    assert d.depth(['cz']) == 4 and d.count_ops() == {'cz': 4, 'rx': 1}
+
+
+def test_project_cp_angles():
+    mask = np.array([0, 0, 1, 0, 1, 1, 1])
+    ang = np.array([1, 2, 0.1, 3, np.pi + 0.15, 1.5, -0.05 + 4 * np.pi], dtype=np.float32)
+    idx, val = project_cp_angles(ang, mask, 0.2)
+    assert idx == [2, 4, 6] and np.allclose(val, [0, np.pi, 0])
+
+
+def test_synthesize_rejects_python_callables():
+    with pytest.raises(NotImplementedError):
+        cpflow_amd.Synthesize([[0, 1]], unitary_loss_func=lambda u: 0.0)
+    with pytest.raises(AssertionError, match='do not match'):
+        cpflow_amd.Synthesize([[0, 1], [1, 2]], target_unitary=np.eye(4))
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from cpflow_amd._ffi import CpfError
+    from cpflow_amd.engine import TemplateEngine
+    with pytest.raises(CpfError, match='no CPU fallback'):
+        TemplateEngine([[0, 1], [1, 2]], 3, np.eye(8))
