@@ -6,11 +6,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/cpflow_amd.h"
 #include "cpf_device.h"
+#include "cpf_fast3.h"
 
 namespace {
 
@@ -44,6 +47,8 @@ struct cpf_plan {
     int device = 0;
     int n = 0, K = 0, n_rot = 0, nb = 0, P = 0, G = 0, T = 0, NQ = 0;
     int entangler = 0;
+    std::string rot;
+    bool force_generic = false;      // CPF_FORCE_GENERIC=1: always use the generic per-gate kernel (A/B testing)
     std::vector<uint8_t> h_pkind;
     std::vector<int4> h_prog;
     DevBuf d_prog, d_target, d_pkind, d_bias;
@@ -112,11 +117,37 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     return 0;
 }
 
+template <int ROT, int PPT>
+int launch_fast3(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    const size_t lds = (size_t)cpf::Fast3Layout::total(K) * sizeof(float);
+    hipLaunchKernelGGL((cpf::k_cp_fast3<ROT, PPT>), dim3((unsigned)S), dim3(64), lds, stream, a);
+    CPF_HIP(hipGetLastError());
+    return 0;
+}
+
+// 3-qubit CP templates with a rotation string the specialised kernel is instantiated for
+// (and few enough angles to keep the optimiser state in registers) take the fast path.
+bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
+        plan->entangler != CPF_ENTANGLER_CP || plan->K > 512)
+        return false;
+    const int ppt = a.P <= 128 ? 2 : (a.P <= 256 ? 4 : 0);
+    if (!ppt) return false;
+    constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
+    constexpr int XZ = cpf::rot_pack(2, cpf::OP_RX, cpf::OP_RZ, 0);
+    if (plan->rot == "xyz") *rc = ppt == 2 ? launch_fast3<XYZ, 2>(a, plan->K, S, stream) : launch_fast3<XYZ, 4>(a, plan->K, S, stream);
+    else if (plan->rot == "xz") *rc = ppt == 2 ? launch_fast3<XZ, 2>(a, plan->K, S, stream) : launch_fast3<XZ, 4>(a, plan->K, S, stream);
+    else return false;
+    return true;
+}
+
 // Variant choice: one workgroup per sample; more waves per sample when there are too few
 // samples to fill 256 CUs x 4 SIMDs and the matrix is large enough to split by columns.
 int launch(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     if (S <= 0) return 0;
     if (S > 0x7fffffffLL) return fail(-21, "num_samples too large");
+    int rc = 0;
+    if (try_fast3(plan, a, S, stream, &rc)) return rc;
     const int64_t simds = (int64_t)plan->num_cu * 4;
     switch (plan->NQ) {
         case 3: return launch_variant<3, 0>(a, S, stream);
@@ -152,6 +183,8 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     pl->nb = 2 * pb->n_rot + (pb->entangler == CPF_ENTANGLER_CP ? 1 : 0);
     pl->P = 3 * pl->n + pl->nb * pl->K;
     pl->T = pb->num_iterations;
+    pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
+    { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
     const int n = pl->n, NQ = pl->NQ, N = 1 << n, D = 1 << NQ, P = pl->P;
 
