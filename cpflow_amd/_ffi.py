@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcpflow_amd.so')
+LIB_PATH = os.environ.get('CPF_LIB') or os.path.join(_HERE, 'libcpflow_amd.so')   # CPF_LIB: A/B builds
 
 ENTANGLER = {'cp': 0, 'cz': 1, 'cx': 2}
 PENALTY = {'linear': 0, 'L1': 1}

@@ -32,6 +32,19 @@ enum : int { MODE_OPTIMIZE = 0, MODE_LOSS_GRAD = 1, MODE_UNITARY = 2 };
 
 struct Piece { float lo, hi, slope, icpt; };
 
+// read-only tables (gate program, bias corrections) are read through the constant address space so
+// that wave-uniform reads become scalar loads (s_load) instead of per-lane global loads
+typedef const float __attribute__((address_space(4)))* const_f_ptr;
+typedef const int __attribute__((address_space(4)))* const_i_ptr;
+__device__ __forceinline__ float2 const_load_f2(const float2* p, int i) {
+    const_f_ptr q = (const_f_ptr)(const float*)p;
+    return make_float2(q[2 * i], q[2 * i + 1]);
+}
+__device__ __forceinline__ int4 const_load_i4(const int4* p, int i) {
+    const_i_ptr q = (const_i_ptr)(const int*)p;
+    return make_int4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+}
+
 struct KArgs {
     const int4* prog;          // [G] {kind, q0, q1, param}
     int G, P, T, mode;
@@ -106,12 +119,18 @@ __device__ __forceinline__ float dpp(float old, float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, ROW_MASK,
                                                       BANK_MASK, false));
 }
+// full-mask DPP read with bound_ctrl: the form GCNDPPCombine folds into the consuming VOP2
+// (v_mul_f32_dpp / v_fmac_f32_dpp / v_add_f32_dpp), so the lane exchange costs no instruction
+template <int CTRL>
+__device__ __forceinline__ float dppz(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
 // value held by lane (lane ^ (1 << BIT))
 template <int BIT>
 __device__ __forceinline__ float xor_lane(float x) {
-    if constexpr (BIT == 0) return dpp<0xB1>(x, x);          // quad_perm:[1,0,3,2]
-    else if constexpr (BIT == 1) return dpp<0x4E>(x, x);     // quad_perm:[2,3,0,1]
-    else if constexpr (BIT == 3) return dpp<0x128>(x, x);    // row_ror:8
+    if constexpr (BIT == 0) return dppz<0xB1>(x);            // quad_perm:[1,0,3,2]
+    else if constexpr (BIT == 1) return dppz<0x4E>(x);       // quad_perm:[2,3,0,1]
+    else if constexpr (BIT == 3) return dppz<0x128>(x);      // row_ror:8
     else if constexpr (BIT == 2) {
         float t = dpp<0x104, 0xF, 0x5>(x, x);                // row_shl:4 -> banks 0,2 read lane+4
         return dpp<0x114, 0xF, 0xA>(t, x);                   // row_shr:4 -> banks 1,3 read lane-4
@@ -119,10 +138,10 @@ __device__ __forceinline__ float xor_lane(float x) {
 }
 // sum over the 64 lanes, returned wave-uniform; fixed order => run-to-run deterministic
 __device__ __forceinline__ float wave_sum(float x) {
-    x += dpp<0xB1>(x, x);
-    x += dpp<0x4E>(x, x);
-    x += dpp<0x124>(x, x);                                   // row_ror:4
-    x += dpp<0x128>(x, x);                                   // row_ror:8 -> every lane holds its row total
+    x += dppz<0xB1>(x);
+    x += dppz<0x4E>(x);
+    x += dppz<0x124>(x);                                     // row_ror:4
+    x += dppz<0x128>(x);                                     // row_ror:8 -> every lane holds its row total
     x += dpp<0x142, 0xA, 0xF>(0.f, x);                       // row_bcast:15 into rows 1,3
     x += dpp<0x143, 0xC, 0xF>(0.f, x);                       // row_bcast:31 into rows 2,3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
@@ -147,14 +166,16 @@ __device__ __forceinline__ void rot_apply(float (&re)[L::E], float (&im)[L::E], 
 #pragma unroll
         for (int e = 0; e < L::E; e++) {
             float nr, ni;
+            // the partner amplitude enters through a plain multiply so that the DPP read folds into it
+            // (v_mul_f32_dpp); hipcc does not fold DPP reads into v_fma / v_fmac operands
             if constexpr (KIND == OP_RX) {
-                float qr = xor_lane<BIT>(re[e]), qi = xor_lane<BIT>(im[e]);
-                nr = fmaf(s, qi, c * re[e]);
-                ni = fmaf(-s, qr, c * im[e]);
+                const float tr_ = s * xor_lane<BIT>(im[e]), ti_ = s * xor_lane<BIT>(re[e]);
+                nr = fmaf(c, re[e], tr_);
+                ni = fmaf(c, im[e], -ti_);
             } else if constexpr (KIND == OP_RY) {
-                float qr = xor_lane<BIT>(re[e]), qi = xor_lane<BIT>(im[e]);
-                nr = fmaf(ss, qr, c * re[e]);
-                ni = fmaf(ss, qi, c * im[e]);
+                const float tr_ = ss * xor_lane<BIT>(re[e]), ti_ = ss * xor_lane<BIT>(im[e]);
+                nr = fmaf(c, re[e], tr_);
+                ni = fmaf(c, im[e], ti_);
             } else {
                 nr = fmaf(-ss, im[e], c * re[e]);
                 ni = fmaf(ss, re[e], c * im[e]);
@@ -191,11 +212,11 @@ __device__ __forceinline__ float rot_grad(const State<L>& st) {
 #pragma unroll
         for (int e = 0; e < L::E; e++) {
             if constexpr (KIND == OP_RX) {
-                float qr = xor_lane<BIT>(st.pr[e]), qi = xor_lane<BIT>(st.pi[e]);
-                u = fmaf(st.cr[e], qi, u); u = fmaf(-st.ci[e], qr, u);
+                const float t1 = st.cr[e] * xor_lane<BIT>(st.pi[e]), t2 = st.ci[e] * xor_lane<BIT>(st.pr[e]);
+                u += t1 - t2;
             } else if constexpr (KIND == OP_RY) {
-                float qr = xor_lane<BIT>(st.pr[e]), qi = xor_lane<BIT>(st.pi[e]);
-                u = fmaf(st.cr[e], qr, u); u = fmaf(st.ci[e], qi, u);
+                const float t1 = st.cr[e] * xor_lane<BIT>(st.pr[e]), t2 = st.ci[e] * xor_lane<BIT>(st.pi[e]);
+                u += t1 + t2;
             } else {
                 u = fmaf(st.cr[e], st.pi[e], u); u = fmaf(-st.ci[e], st.pr[e], u);
             }
@@ -332,10 +353,15 @@ __device__ __forceinline__ float op_backward(int kind, int q0, int q1, float c, 
 }
 
 // ------------------------------------------------------------------ penalty (penalty.py:44-71)
+// jnp.mod(a, float32(2 pi)) (floored).  a - floor(a/c) c in one fma is the exactly rounded value of
+// the true remainder (what fmod + the reference's sign fix-up produce); the fix-up lines only
+// act when the float32 quotient estimate is off by one.
 __device__ __forceinline__ float floor_mod_2pi(float a) {
     const float twopi = 6.2831855f;
-    float r = fmodf(a, twopi);
-    if (r != 0.f && r < 0.f) r += twopi;
+    const float k = floorf(a * 0.15915494f);
+    float r = fmaf(-k, twopi, a);
+    if (r < 0.f) r += twopi;
+    else if (r >= twopi) r -= twopi;
     return r;
 }
 __device__ __forceinline__ float penalty_value(const KArgs& a, float ang, float& slope) {
@@ -344,11 +370,12 @@ __device__ __forceinline__ float penalty_value(const KArgs& a, float ang, float&
         return fabsf(ang);
     }
     const float x = floor_mod_2pi(ang);
-    float sl = 0.f, ic = 0.f;
-    if (x <= a.pc[0].hi) { sl = a.pc[0].slope; ic = a.pc[0].icpt; }
+    // the (lo, hi] pieces tile [0, 2 pi] and x lies in it, so "last true condition wins"
+    // is the last piece whose lower break point is below x
+    float sl = a.pc[0].slope, ic = a.pc[0].icpt;
 #pragma unroll
-    for (int i = 1; i < 10; i++)
-        if (a.pc[i].lo < x && x <= a.pc[i].hi) { sl = a.pc[i].slope; ic = a.pc[i].icpt; }   // last true wins
+    for (int i = 1; i < 9; i++)
+        if (x > a.pc[i].lo) { sl = a.pc[i].slope; ic = a.pc[i].icpt; }
     slope = sl;
     return __fadd_rn(__fmul_rn(sl, x), ic);
 }

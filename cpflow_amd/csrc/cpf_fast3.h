@@ -24,8 +24,10 @@ __host__ __device__ constexpr int rot_nr(int rot) { return rot & 15; }
 __host__ __device__ constexpr int rot_kind(int rot, int i) { return (rot >> (4 + 4 * i)) & 15; }
 
 struct Fast3Layout {                  // LDS float offsets
-    static constexpr int SURF_CS = 0;     // 9 x (c, s) = 18 floats, padded to 20
-    static constexpr int BLK_CS = 20;     // + 16 * b : 7 x (c, s), [14] = pair code, [15] pad
+    static constexpr int PEN_LO = 0;      // 8 lower break points of penalty pieces 1..8
+    static constexpr int PEN_SI = 8;      // 9 x (slope, intercept), padded to 20 floats
+    static constexpr int SURF_CS = 28;    // 9 x (c, s) = 18 floats, padded to 20
+    static constexpr int BLK_CS = 48;     // + 16 * b : 7 x (c, s), [14] = pair code, [15] pad
     __host__ __device__ static constexpr int g_base(int K) { return BLK_CS + 16 * K; }
     // gradient slabs: [k][row] floats; surface 16 k, block 8 k, 4 rows each
     __host__ __device__ static constexpr int g_surf(int K) { return g_base(K); }
@@ -38,23 +40,23 @@ using L3 = Lay<3, 0>;
 // reduce 8 per-lane values over the 64 lanes; afterwards dst[k*4 + row] (row = lane >> 4) holds the
 // partial sum of d[k] over the 16 lanes of that row.  Stages: scatter over lane bits 0,1 (quad_perm),
 // bit 2 (row_shl/shr:4), then add over bit 3 (row_ror:8).  Rows are added by the reader.
-__device__ __forceinline__ void reduce8_rows(const float (&d)[8], float* dst, int lane) {
+__device__ __forceinline__ void reduce8_rows(const float (&d)[8], float* dst, int lane, int dst_lane) {
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
     float e[4], f[2];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float keep = b0 ? d[2 * i + 1] : d[2 * i], give = b0 ? d[2 * i] : d[2 * i + 1];
-        e[i] = keep + dpp<0xB1>(give, give);
+        e[i] = keep + dppz<0xB1>(give);
     }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const float keep = b1 ? e[2 * i + 1] : e[2 * i], give = b1 ? e[2 * i] : e[2 * i + 1];
-        f[i] = keep + dpp<0x4E>(give, give);
+        f[i] = keep + dppz<0x4E>(give);
     }
     const float keep = b2 ? f[1] : f[0], give = b2 ? f[0] : f[1];
     float r = keep + xor_lane<2>(give);
-    r += dpp<0x128>(r, r);
-    dst[(lane & 7) * 4 + (lane >> 4)] = r;       // lanes l and l^8 store the same value to the same word
+    r += dppz<0x128>(r);
+    dst[dst_lane] = r;       // dst_lane = (lane & 7) * 4 + (lane >> 4); lanes l and l^8 store the same value to the same word
 }
 
 template <int KIND, int Q>
@@ -108,6 +110,23 @@ __device__ __forceinline__ void f3_block_bwd(State<L3>& st, const float (&r)[16]
     cp_apply<L3, Q0, Q1>(st.cr, st.ci, cc, -sc, st);
 }
 
+// penalty.py:44-71 from an LDS copy of the piece table: count the break points below x, then ONE
+// per-lane LDS read of that piece's (slope, intercept).  (Selecting among kernel-argument fields
+// made hipcc select the field ADDRESS and issue a global load from the kernarg segment per lane.)
+__device__ __forceinline__ float penalty_lds(const float* smem, int pen_kind, float ang, float& slope) {
+    if (pen_kind == 1) {
+        slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
+        return fabsf(ang);
+    }
+    const float x = floor_mod_2pi(ang);
+    const float4 l0 = *reinterpret_cast<const float4*>(smem + Fast3Layout::PEN_LO);
+    const float4 l1 = *reinterpret_cast<const float4*>(smem + Fast3Layout::PEN_LO + 4);
+    const int idx = (x > l0.x) + (x > l0.y) + (x > l0.z) + (x > l0.w) + (x > l1.x) + (x > l1.y) + (x > l1.z) + (x > l1.w);
+    const float2 si = *reinterpret_cast<const float2*>(smem + Fast3Layout::PEN_SI + 2 * idx);
+    slope = si.x;
+    return __fadd_rn(__fmul_rn(si.x, x), si.y);
+}
+
 __device__ __forceinline__ void load_rec(const float* p, float (&r)[16]) {
     const float4* q = reinterpret_cast<const float4*>(p);
     const float4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -115,10 +134,31 @@ __device__ __forceinline__ void load_rec(const float* p, float (&r)[16]) {
     r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w; r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
 }
 
+// One wave per workgroup: a wave's LDS operations execute in order, so a write followed by a read
+// needs no s_barrier and no wait on outstanding GLOBAL stores (which __syncthreads() would add:
+// the best-angle / history stores are fire-and-forget).  Only the compiler must keep the order.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 #define CPF_F3_PAIRS(M) M(0, 1) M(1, 0) M(0, 2) M(2, 0) M(1, 2) M(2, 1)
 
-template <int ROT, int PPT>
+// LAYER: the connectivity layer as a compile-time sequence of (up, dn) pairs
+//   L | up0 << 4 | dn0 << 6 | up1 << 8 | dn1 << 10 | up2 << 12 | dn2 << 14       (L <= 3), or 0 = any layer.
+// With a known layer the block loop runs layer by layer over straight-line code; with LAYER = 0 every block
+// dispatches on its pair code through a branch tree, which measured 22 % slower on config 2
+// (143 extra branches per step at ~19 cycles each, plus the register moves that merge the cases).
+__host__ __device__ constexpr int layer_pack(int L, int u0, int d0, int u1, int d1, int u2, int d2) {
+    return L | (u0 << 4) | (d0 << 6) | (u1 << 8) | (d1 << 10) | (u2 << 12) | (d2 << 14);
+}
+__host__ __device__ constexpr int layer_len(int layer) { return layer & 15; }
+__host__ __device__ constexpr int layer_up(int layer, int i) { return (layer >> (4 + 4 * i)) & 3; }
+__host__ __device__ constexpr int layer_dn(int layer, int i) { return (layer >> (6 + 4 * i)) & 3; }
+
+template <int ROT, int PPT, int LAYER>
 __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
+    constexpr int LL = layer_len(LAYER);
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -135,16 +175,27 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
     const float2 tgt = a.target[row * 8 + col];
     const float vr = tgt.x, vi = tgt.y;
     const bool diag = (row == col);
+    const int dst_lane = (lane & 7) * 4 + (lane >> 4);
 
-    // ---- owner state: parameter j = lane + 64 * s
+    // ---- owner state.  Owner slot o = lane + 64 * s holds parameter pj[s]; the K CP angles come first
+    //      (o < K -> CP angle of block o), so that for K <= 64 only slot 0 evaluates the penalty.
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
-    int cs_off[PPT], g_off[PPT];
+    int cs_off[PPT], g_off[PPT], pj[PPT];
     bool valid[PPT], is_cp[PPT], frz[PPT];
+    if (lane < 8) smem[Fast3Layout::PEN_LO + lane] = a.pc[lane + 1].lo;
+    if (lane < 9) { smem[Fast3Layout::PEN_SI + 2 * lane] = a.pc[lane].slope; smem[Fast3Layout::PEN_SI + 2 * lane + 1] = a.pc[lane].icpt; }
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
-        const int j = lane + 64 * s;
-        valid[s] = j < P;
-        const int jj = valid[s] ? j : 0;
+        const int o = lane + 64 * s;
+        valid[s] = o < P;
+        int j = 0;
+        if (valid[s]) {
+            if (o < K) j = 9 + NB * o + NB - 1;
+            else if (o - K < 9) j = o - K;
+            else { const int q = o - K - 9; j = 9 + NB * (q / (NB - 1)) + q % (NB - 1); }
+        }
+        pj[s] = j;
+        const int jj = j;
         is_cp[s] = valid[s] && a.pkind[jj];
         frz[s] = valid[s] && frozen && frozen[jj];
         if (jj < 9) { cs_off[s] = Fast3Layout::SURF_CS + 2 * jj; g_off[s] = Fast3Layout::g_surf(K) + 4 * jj; }
@@ -156,6 +207,7 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
         mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
         if (valid[s]) { a.out_params[(s_idx * 2) * P + jj] = th[s]; out_best[jj] = th[s]; }
     }
+    const bool slot_has_cp[4] = {K > 0, K > 64, K > 128, K > 192};
     // block pair codes: record slot 14 (static for the whole run)
     for (int b = lane; b < K; b += 64) {
         const int4 op = a.prog[9 + b * NB];                      // the block's CP op {kind, lo, hi, param}; up/dn from the next op
@@ -168,8 +220,9 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
         float sn, cn;
         sincosf(is_cp[s] ? th[s] : 0.5f * th[s], &sn, &cn);
         if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
-        if (a.use_reg && is_cp[s]) { float sl; pval[s] = penalty_value(a, th[s], sl); psl[s] = a.r * sl; }
+        if (a.use_reg && slot_has_cp[s] && is_cp[s]) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
     };
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < PPT; s++) publish(s);
     __syncthreads();
@@ -177,6 +230,7 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
+        const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);   // scalar load, issued early, consumed by the Adam phase
         // ================= forward
         st.pr[0] = diag ? 1.f : 0.f; st.pi[0] = 0.f;
         {
@@ -191,18 +245,36 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
         if (K > 0) {
             float rc[16];
             load_rec(smem + Fast3Layout::BLK_CS, rc);
-            for (int b = 0; b < K; b++) {
-                float rn[16];
-                load_rec(smem + Fast3Layout::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rn);     // prefetch next record
-                const int pair = __builtin_amdgcn_readfirstlane(__float_as_int(rc[14]));
-                switch (pair) {
+            if constexpr (LL == 0) {
+                for (int b = 0; b < K; b++) {
+                    float rn[16];
+                    load_rec(smem + Fast3Layout::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rn);     // prefetch next record
+                    const int pair = __builtin_amdgcn_readfirstlane(__float_as_int(rc[14]));
+                    switch (pair) {
 #define CPF_F3_CASE(U, D) case U * 4 + D: f3_block_fwd<U, D, ROT>(st, rc); break;
-                    CPF_F3_PAIRS(CPF_F3_CASE)
+                        CPF_F3_PAIRS(CPF_F3_CASE)
 #undef CPF_F3_CASE
-                    default: break;
-                }
+                        default: break;
+                    }
 #pragma unroll
-                for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                    for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                }
+            } else {
+                // block b = l * LL + i sits on pair i of the layer (topology.py:15-20)
+#define CPF_F3_FWD_STEP(I)                                                                              \
+                if (b < K) {                                                                            \
+                    float rn[16];                                                                       \
+                    load_rec(smem + Fast3Layout::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rn);            \
+                    f3_block_fwd<layer_up(LAYER, I), layer_dn(LAYER, I), ROT>(st, rc);                  \
+                    _Pragma("unroll") for (int i = 0; i < 16; i++) rc[i] = rn[i];                       \
+                    b++;                                                                                \
+                }
+                for (int b = 0; b < K;) {
+                    CPF_F3_FWD_STEP(0)
+                    if constexpr (LL > 1) { CPF_F3_FWD_STEP(1) }
+                    if constexpr (LL > 2) { CPF_F3_FWD_STEP(2) }
+                }
+#undef CPF_F3_FWD_STEP
             }
         }
         // ================= loss, penalty, best tracking
@@ -223,11 +295,11 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
         else if (regloss < best) { best = regloss; improved = true; }
         if (improved) {
 #pragma unroll
-            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[lane + 64 * s] = th[s];
+            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
         }
         if (a.hist_params) {
 #pragma unroll
-            for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + lane + 64 * s] = th[s];
+            for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + pj[s]] = th[s];
             if (lane == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         }
         if (a.T == 0) break;
@@ -241,19 +313,43 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
         if (K > 0) {
             float rc[16], d[8];
             load_rec(smem + Fast3Layout::BLK_CS + 16 * (K - 1), rc);
-            for (int b = K - 1; b >= 0; b--) {
-                float rn[16];
-                load_rec(smem + Fast3Layout::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rn);
-                const int pair = __builtin_amdgcn_readfirstlane(__float_as_int(rc[14]));
-                switch (pair) {
+            if constexpr (LL == 0) {
+                for (int b = K - 1; b >= 0; b--) {
+                    float rn[16];
+                    load_rec(smem + Fast3Layout::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rn);
+                    const int pair = __builtin_amdgcn_readfirstlane(__float_as_int(rc[14]));
+                    switch (pair) {
 #define CPF_F3_CASE(U, D) case U * 4 + D: f3_block_bwd<U, D, ROT>(st, rc, d); break;
-                    CPF_F3_PAIRS(CPF_F3_CASE)
+                        CPF_F3_PAIRS(CPF_F3_CASE)
 #undef CPF_F3_CASE
-                    default: break;
-                }
-                reduce8_rows(d, smem + Fast3Layout::g_blk(K, b), lane);
+                        default: break;
+                    }
+                    reduce8_rows(d, smem + Fast3Layout::g_blk(K, b), lane, dst_lane);
 #pragma unroll
-                for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                    for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                }
+            } else {
+#define CPF_F3_BWD_STEP(I)                                                                              \
+                {                                                                                       \
+                    float rn[16];                                                                       \
+                    load_rec(smem + Fast3Layout::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rn);                \
+                    f3_block_bwd<layer_up(LAYER, I), layer_dn(LAYER, I), ROT>(st, rc, d);               \
+                    reduce8_rows(d, smem + Fast3Layout::g_blk(K, b), lane, dst_lane);                   \
+                    _Pragma("unroll") for (int i = 0; i < 16; i++) rc[i] = rn[i];                       \
+                    b--;                                                                                \
+                }
+                int b = K - 1;
+                // the truncated last layer first (its blocks sit on pairs 0 .. K % LL - 1), then full layers
+                const int rem = K % LL;
+                if constexpr (LL > 2) { if (rem > 2) CPF_F3_BWD_STEP(2) }
+                if constexpr (LL > 1) { if (rem > 1) CPF_F3_BWD_STEP(1) }
+                if (rem > 0) CPF_F3_BWD_STEP(0)
+                while (b >= 0) {
+                    if constexpr (LL > 2) { CPF_F3_BWD_STEP(2) }
+                    if constexpr (LL > 1) { CPF_F3_BWD_STEP(1) }
+                    CPF_F3_BWD_STEP(0)
+                }
+#undef CPF_F3_BWD_STEP
             }
         }
         {
@@ -266,13 +362,13 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
             d2[0] = f3_rot_bwd<OP_RZ, 2>(st, sr[16], sr[17]); d[7] = f3_rot_bwd<OP_RX, 2>(st, sr[14], sr[15]); d[6] = f3_rot_bwd<OP_RZ, 2>(st, sr[12], sr[13]);
             d[5] = f3_rot_bwd<OP_RZ, 1>(st, sr[10], sr[11]);  d[4] = f3_rot_bwd<OP_RX, 1>(st, sr[8], sr[9]);   d[3] = f3_rot_bwd<OP_RZ, 1>(st, sr[6], sr[7]);
             d[2] = f3_rot_bwd<OP_RZ, 0>(st, sr[4], sr[5]);    d[1] = f3_rot_bwd<OP_RX, 0>(st, sr[2], sr[3]);   d[0] = f3_rot_bwd<OP_RZ, 0>(st, sr[0], sr[1]);
-            reduce8_rows(d, smem + Fast3Layout::g_surf(K), lane);
-            reduce8_rows(d2, smem + Fast3Layout::g_surf(K) + 32, lane);
+            reduce8_rows(d, smem + Fast3Layout::g_surf(K), lane, dst_lane);
+            reduce8_rows(d2, smem + Fast3Layout::g_surf(K) + 32, lane, dst_lane);
         }
-        __syncthreads();
+        wave_lds_fence();
 
         // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner lanes
-        const float2 bc = a.bias[it];
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
             const float4 gp = *reinterpret_cast<const float4*>(smem + g_off[s]);
@@ -282,11 +378,12 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
                 const float m = fmaf(a.b1, mm[s], a.omb1 * g);
                 const float v = fmaf(a.b2, vv[s], a.omb2 * (g * g));
                 mm[s] = m; vv[s] = v;
-                th[s] = fmaf(-a.lr, (m / bc.x) / (sqrtf(v / bc.y) + a.eps), th[s]);
+                // hardware sqrt / rcp (1 ulp): the step error is ~1e-8, below the angle's own ulp
+                th[s] = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[s]);
             }
             publish(s);
         }
-        __syncthreads();
+        wave_lds_fence();
     }
 
     // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164)
@@ -295,10 +392,10 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
         if (is_cp[s]) {
-            const int j = lane + 64 * s;
+            const int j = pj[s];
             const float t0 = a.out_params[(s_idx * 2) * P + j], t1 = out_best[j];
             float sl;
-            if (a.use_reg) { acc0 += penalty_value(a, t0, sl); acc1 += penalty_value(a, t1, sl); }
+            if (a.use_reg) { acc0 += penalty_lds(smem, a.pen_kind, t0, sl); acc1 += penalty_lds(smem, a.pen_kind, t1, sl); }
             acc2 += cz_value(bi ? t1 : t0, a.thr_cp);
         }
     }

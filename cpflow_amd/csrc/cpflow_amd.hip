@@ -48,6 +48,7 @@ struct cpf_plan {
     int n = 0, K = 0, n_rot = 0, nb = 0, P = 0, G = 0, T = 0, NQ = 0;
     int entangler = 0;
     std::string rot;
+    int layer_code = 0;              // packed (up, dn) sequence when the placements cycle through <= 3 pairs
     bool force_generic = false;      // CPF_FORCE_GENERIC=1: always use the generic per-gate kernel (A/B testing)
     std::vector<uint8_t> h_pkind;
     std::vector<int4> h_prog;
@@ -117,12 +118,22 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     return 0;
 }
 
-template <int ROT, int PPT>
+template <int ROT, int PPT, int LAYER>
 int launch_fast3(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
     const size_t lds = (size_t)cpf::Fast3Layout::total(K) * sizeof(float);
-    hipLaunchKernelGGL((cpf::k_cp_fast3<ROT, PPT>), dim3((unsigned)S), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((cpf::k_cp_fast3<ROT, PPT, LAYER>), dim3((unsigned)S), dim3(64), lds, stream, a);
     CPF_HIP(hipGetLastError());
     return 0;
+}
+
+template <int ROT, int PPT>
+int launch_fast3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+    // the two layer constructors of the reference for 3 qubits (topology.py:7-12) get straight-line code
+    constexpr int CHAIN = cpf::layer_pack(2, 0, 1, 1, 2, 0, 0);
+    constexpr int CONN = cpf::layer_pack(3, 0, 1, 0, 2, 1, 2);
+    if (plan->layer_code == CHAIN) return launch_fast3<ROT, PPT, CHAIN>(a, plan->K, S, stream);
+    if (plan->layer_code == CONN) return launch_fast3<ROT, PPT, CONN>(a, plan->K, S, stream);
+    return launch_fast3<ROT, PPT, 0>(a, plan->K, S, stream);
 }
 
 // 3-qubit CP templates with a rotation string the specialised kernel is instantiated for
@@ -135,8 +146,8 @@ bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t
     if (!ppt) return false;
     constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
     constexpr int XZ = cpf::rot_pack(2, cpf::OP_RX, cpf::OP_RZ, 0);
-    if (plan->rot == "xyz") *rc = ppt == 2 ? launch_fast3<XYZ, 2>(a, plan->K, S, stream) : launch_fast3<XYZ, 4>(a, plan->K, S, stream);
-    else if (plan->rot == "xz") *rc = ppt == 2 ? launch_fast3<XZ, 2>(a, plan->K, S, stream) : launch_fast3<XZ, 4>(a, plan->K, S, stream);
+    if (plan->rot == "xyz") *rc = ppt == 2 ? launch_fast3_layer<XYZ, 2>(plan, a, S, stream) : launch_fast3_layer<XYZ, 4>(plan, a, S, stream);
+    else if (plan->rot == "xz") *rc = ppt == 2 ? launch_fast3_layer<XZ, 2>(plan, a, S, stream) : launch_fast3_layer<XZ, 4>(plan, a, S, stream);
     else return false;
     return true;
 }
@@ -213,6 +224,20 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
         }
     }
     pl->G = (int)prog.size();
+    // periodic placements with period <= 3 -> compile-time layer code for the 3-qubit kernel
+    pl->layer_code = 0;
+    if (n == 3 && pl->K > 0) {
+        for (int L = 1; L <= 3 && !pl->layer_code; L++) {
+            bool periodic = true;
+            for (int b = L; b < pl->K && periodic; b++)
+                periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
+                           pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
+            if (!periodic) continue;
+            int pr[6] = {0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < L && i < pl->K; i++) { pr[2 * i] = pb->placements[2 * i]; pr[2 * i + 1] = pb->placements[2 * i + 1]; }
+            if (pl->K >= L) pl->layer_code = cpf::layer_pack(L, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5]);
+        }
+    }
 
     // ---- target, used as complex64, embedded as V (x) I when the kernel is wider than the problem
     std::vector<float2> tgt((size_t)D * D, make_float2(0.f, 0.f));
