@@ -124,6 +124,12 @@ def main():
         achieved_tf = flops * S_local * T / (k_ms * 1e-3) / 1e12
         P = eng.num_angles
         alg_bytes = S_local * (8 * P + 28) + 8 * 8 * 8         # persistent model: theta0 in, best theta + scalars out
+        traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_v2_pmc_summary.json')) as f:
+                traffic = json.load(f)['traffic_bytes_per_launch'] if S_local == 1024 else None
+        except Exception:
+            pass
         line = {
             'metric': 'optimizer steps/sec x num_samples (sample-steps/s), 3q CCZ synth',
             'value': value, 'unit': 'sample-steps/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
@@ -133,7 +139,7 @@ def main():
                                    f'({S_total} total), num_gd_iterations={T}, lr=0.1, r={r}, seed={seed}, xyz',
                        'parallelism': f'sample-sharded x{n_gpus}', 'passed_entry_loss': int(summary['passed'].sum())},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / FP32_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved_tf / FP32_PEAK_TFLOPS, 'traffic': traffic,
                          'note': 'fp32 vector ALU work (no MFMA used); peak = f32 vector = f32 MFMA dense peak; '
                                  f'kernel {k_ms:.3f} ms per launch (HIP events), {flops:.0f} flop/sample-step'},
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes,
