@@ -165,3 +165,49 @@ def test_full_size_properties(cfg):
     if cfg == 'cfg2':
         assert out['passed'].mean() > 0.5
         assert out['cz'][out['passed']].min() <= 8
+
+
+def test_adaptive_front_end_small(tmp_path):
+    """Adaptive routine end to end (own TPE instead of hyperopt): seed chain as the reference, trials saved
+    after every evaluation, resume continues the chain, found decompositions verify to target_loss."""
+    from cpflow_amd import AdaptiveOptions, Results, Synthesize
+    from cpflow_amd import prng
+    opts = AdaptiveOptions(min_num_cp_gates=8, max_num_cp_gates=14, max_evals=3, num_samples=24,
+                           target_num_cz_gates=8, stop_if_target_reached=False)
+    path = str(tmp_path / 'res' / 'toff3')
+    syn = Synthesize([[0, 1], [1, 2]], target_unitary=TOFF3, label='toff3')
+    res = syn.adaptive(opts, save_to=path)
+    assert len(res.trials.results) == 3
+    seed = 0
+    for r in res.trials.results:
+        seed = prng.next_adaptive_seed(seed)
+        assert r['random_seed'] == seed and 8 <= r['num_cp_gates'] <= 14
+        assert 'prospective_decompositions' not in r
+    for d in res.decompositions:
+        assert d.loss < 1e-5 and d._adaptive_options is opts
+    back = Results.load(path)
+    assert len(back.trials.results) == 3
+    opts.max_evals = 4
+    res2 = Synthesize([[0, 1], [1, 2]], target_unitary=TOFF3, label='toff3').adaptive(opts, save_to=path)
+    assert len(res2.trials.results) == 4
+    assert res2.trials.results[3]['random_seed'] == prng.next_adaptive_seed(seed)
+
+
+def test_ansatz_unitary_circuit_and_learn():
+    """Ansatz.unitary == the circuit IR's own unitary; a 'cz' template learns a reachable target."""
+    from cpflow_amd import Ansatz, fill_layers
+    rng = np.random.default_rng(5)
+    for ent, rot in (('cp', 'xyz'), ('cz', 'xz')):
+        anz = Ansatz(3, ent, fill_layers([[0, 1], [2, 1], [0, 2]], 5), rot)
+        th = rng.uniform(0, 2 * np.pi, anz.num_angles).astype(np.float32)
+        u = anz.unitary(th)
+        ref = anz.circuit(th).unitary()
+        assert np.abs(u - ref).max() < 5e-6
+    anz = Ansatz(3, 'cz', fill_layers([[0, 1], [1, 2]], 4))
+    target = anz.circuit(rng.uniform(0, 2 * np.pi, anz.num_angles)).unitary()
+    out = anz.learn(target, num_iterations=1500, num_repeats=8, keep_history=False)
+    assert len(out) == 8 and out[0]['params'].shape == (2, anz.num_angles)
+    assert min(o['loss'][1] for o in out) < 1e-3
+    hist = anz.learn(target, num_iterations=50, initial_angles=out[0]['params'][0])
+    assert hist['params'].shape == (50, anz.num_angles) and hist['loss'].shape == (50,)
+    assert (hist['params'][0] == out[0]['params'][0]).all()

@@ -114,3 +114,47 @@ def test_engine_fails_loudly_without_gpu():
     from cpflow_amd.engine import TemplateEngine
     with pytest.raises(CpfError, match='no CPU fallback'):
         TemplateEngine([[0, 1], [1, 2]], 3, np.eye(8))
+
+
+def test_adaptive_search_pieces(golden_dir):
+    from cpflow_amd import prng
+    from cpflow_amd.hyper import Trials, score_from_cz_counts, suggest
+    g = np.load(os.path.join(golden_dir, 'raw_toff3_chain_t49.npz'))
+    assert abs(score_from_cz_counts(g['cz_counts'], 100) - float(g['score'])) < 1e-6     # stored hyperopt loss
+    assert score_from_cz_counts([], 100) == float('inf')
+    a = np.load(os.path.join(golden_dir, 'adaptive_toff4_star.npz'))
+    seed = int(a['initial_seed'])
+    for stored in a['seeds'][:10]:
+        seed = prng.next_adaptive_seed(seed)
+        assert seed == int(stored)
+    rng = np.random.default_rng(3)
+    hist = []
+    for _ in range(45):
+        k, r = suggest(rng, hist, 5, 25, 0.00055, 0.5)
+        assert 5 <= k <= 25 and r > 0
+        hist.append((k, r, float(abs(k - 12))))
+    assert np.mean([k for k, _, _ in hist[-15:]]) < np.mean([k for k, _, _ in hist[:15]]) + 4
+    t = Trials()
+    t.append({'num_cp_gates': 7, 'r': 0.1}, {'loss': 3.0, 'num_cp_gates': 7, 'r': 0.1})
+    t.append({'num_cp_gates': 9, 'r': 0.2}, {'loss': 1.0, 'num_cp_gates': 9, 'r': 0.2})
+    res = cpflow_amd.Results(None, [[0, 1]], label='x', trials=t)
+    assert res.best_hyperparameters() == [[9, 0.2], [7, 0.1]] and res.save_to == 'results/x'
+
+
+def test_refine_reduces_and_rationalises():
+    from cpflow_amd.synthesis import Decomposition
+    qc = Circuit(2).rz(np.pi / 4, 0).rx(0.3, 0).rx(-0.3, 0).cz(0, 1).rz(np.pi / 2 + 1e-4, 1).cp(np.pi, 0, 1)
+    d = Decomposition(HSTLoss(qc.unitary()), qc, label='t')
+    assert d.cz_count == 1 and d.type == 'Approximate'
+    assert d.refine() == 'Refined to Rational'
+    assert d.type == 'Rational' and d.cz_count == 2 and d.loss < 1e-6
+    assert all(n != 'rx' for n, _, _ in d.circuit.data)
+
+
+def test_results_roundtrip(tmp_path):
+    d = cpflow_amd.Decomposition(HSTLoss(np.eye(4)), Circuit(2).cz(0, 1).cz(0, 1), label='id')
+    res = cpflow_amd.Results(HSTLoss(np.eye(4)), [[0, 1]], label='id', decompositions=[d], save_to=str(tmp_path / 'r' / 'id'))
+    res.save()
+    back = cpflow_amd.Results.load(str(tmp_path / 'r' / 'id'))
+    assert repr(back.decompositions[0]) == repr(d) and back.layer == [[0, 1]]
+    assert back.decompositions[0].loss < 1e-12
