@@ -8,7 +8,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'cpf_device.h'), os.path.join(HERE, 'csrc', 'cpf_fast3.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
+DEPS = [SRC, os.path.join(HERE, 'csrc', 'cpf_device.h'), os.path.join(HERE, 'csrc', 'cpf_fast3.h'),
+        os.path.join(HERE, 'csrc', 'cpf_layered.h'), os.path.join(HERE, 'csrc', 'cpf_jit.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
 OUT = os.path.join(HERE, 'libcpflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_*_f32 with extra moves,
@@ -24,7 +25,7 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [HIPCC] + FLAGS + ['-o', OUT, SRC]
+    cmd = [HIPCC] + FLAGS + ['-o', OUT, SRC, '-lhiprtc']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

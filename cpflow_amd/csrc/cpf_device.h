@@ -22,8 +22,16 @@
 // (1/2) sum Im(conj(C) sigma psi) taken right after the gate, then both psi and C are
 // multiplied by the gate's inverse.  No intermediate unitaries are stored.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else      // hiprtc: the runtime header is built in, the fixed-width names are not
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#endif
 
 namespace cpf {
 
@@ -51,6 +59,7 @@ struct KArgs {
     int n_actual;              // problem qubits (<= kernel qubits; spectators are the low bits)
     const float2* target;      // [D][D] embedded target, D = 2^NQ
     const uint8_t* pkind;      // [P] 1 = CP angle (full angle, penalised), 0 = rotation (half angle)
+    const int32_t* pgate;      // [P] index of the gate that carries angle j
     const float2* bias;        // [T] {1 - b1^t, 1 - b2^t}, t = 1..T
     Piece pc[10];
     int pen_kind, use_reg;
@@ -364,20 +373,28 @@ __device__ __forceinline__ float floor_mod_2pi(float a) {
     else if (r >= twopi) r -= twopi;
     return r;
 }
-__device__ __forceinline__ float penalty_value(const KArgs& a, float ang, float& slope) {
-    if (a.pen_kind == 1) {                                    // penalty.py:74-76
+// LDS copy of the piece table: 8 lower break points (pieces 1..8), then 9 x (slope, intercept); 28 floats.
+// Selecting among kernel-argument fields made hipcc select the field ADDRESS and issue a per-lane global
+// load from the kernarg segment, so the table is staged in LDS once and read with one per-lane ds_read.
+constexpr int PEN_LO = 0, PEN_SI = 8, PEN_FLOATS = 28;
+__device__ __forceinline__ void penalty_table_init(float* tab, const KArgs& a, int tid) {
+    if (tid < 8) tab[PEN_LO + tid] = a.pc[tid + 1].lo;
+    if (tid < 9) { tab[PEN_SI + 2 * tid] = a.pc[tid].slope; tab[PEN_SI + 2 * tid + 1] = a.pc[tid].icpt; }
+}
+// the (lo, hi] pieces tile [0, 2 pi] and x lies in it, so jnp.piecewise's "last true condition wins"
+// is the piece whose index is the number of break points below x
+__device__ __forceinline__ float penalty_lds(const float* tab, int pen_kind, float ang, float& slope) {
+    if (pen_kind == 1) {                                      // penalty.py:74-76
         slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
         return fabsf(ang);
     }
     const float x = floor_mod_2pi(ang);
-    // the (lo, hi] pieces tile [0, 2 pi] and x lies in it, so "last true condition wins"
-    // is the last piece whose lower break point is below x
-    float sl = a.pc[0].slope, ic = a.pc[0].icpt;
-#pragma unroll
-    for (int i = 1; i < 9; i++)
-        if (x > a.pc[i].lo) { sl = a.pc[i].slope; ic = a.pc[i].icpt; }
-    slope = sl;
-    return __fadd_rn(__fmul_rn(sl, x), ic);
+    const float4 l0 = *reinterpret_cast<const float4*>(tab + PEN_LO);
+    const float4 l1 = *reinterpret_cast<const float4*>(tab + PEN_LO + 4);
+    const int idx = (x > l0.x) + (x > l0.y) + (x > l0.z) + (x > l0.w) + (x > l1.x) + (x > l1.y) + (x > l1.z) + (x > l1.w);
+    const float2 si = *reinterpret_cast<const float2*>(tab + PEN_SI + 2 * idx);
+    slope = si.x;
+    return __fadd_rn(__fmul_rn(si.x, x), si.y);
 }
 // cp_utils.py:45-50 cz_value
 __device__ __forceinline__ float cz_value(float ang, float t) {
@@ -390,18 +407,32 @@ __device__ __forceinline__ float cz_value(float ang, float t) {
     return v;
 }
 
-// ------------------------------------------------------------------ workgroup reductions
+// ------------------------------------------------------------------ workgroup synchronisation
+// LDS hand-offs inside one workgroup.  One wave: a wave's LDS operations execute in order, so only the
+// compiler has to keep the order.  Several waves: wait for this wave's LDS operations, then s_barrier —
+// NOT __syncthreads(), whose fence also waits for outstanding global stores (best-angle / history rows),
+// which are fire-and-forget here.
+template <int WPS>
+__device__ __forceinline__ void lds_sync() {
+    if constexpr (WPS == 1) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 template <class L, int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int wave, int lane) {
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
     if constexpr (L::WPS > 1) {
-        __syncthreads();                                  // previous readers of red are done
+        lds_sync<L::WPS>();                               // previous readers of red are done
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
         }
-        __syncthreads();
+        lds_sync<L::WPS>();
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             float s = 0.f;
@@ -412,25 +443,38 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int wave, 
     }
 }
 
-__host__ __device__ inline size_t lds_floats(int P, int wps) {
-    // theta, m, v, pen-slope, cs(2), grad slots(wps), reduction scratch
-    return (size_t)P * (6 + wps) + 16 * wps;
-}
+// LDS map of the generic kernel (float offsets)
+struct GenLds {
+    int rec, th, mm, vv, psl, gw, red, total;
+    __host__ __device__ GenLds(int P, int G, int wps) {
+        rec = PEN_FLOATS;                 // G x {cos, sin, code, -}: one broadcast ds_read_b128 per gate
+        th = rec + 4 * G;                 // theta, Adam m, v, r * penalty slope: owner state, P each
+        mm = th + P; vv = mm + P; psl = vv + P;
+        gw = psl + P;                     // [wps][G] per-wave gradient of the gate's angle
+        red = gw + wps * G;
+        total = red + 8 * wps + 4;
+    }
+};
+__host__ __device__ inline size_t lds_floats(int P, int G, int wps) { return (size_t)GenLds(P, G, wps).total; }
 
-// ------------------------------------------------------------------ the kernel
+// ------------------------------------------------------------------ the generic kernel
+// One workgroup (1 or 4 waves) per sample, any n <= 6, any rotation string, CP or CZ entangler.
+// Per gate: one 16-byte LDS record {cos, sin, opcode} prefetched one gate ahead, dispatch on
+// (kind, qubit), and in the backward sweep one wave reduction of the gate's gradient share.
 template <int NQ, int LW>
 __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
     using L = Lay<NQ, LW>;
     constexpr int E = L::E;
-    extern __shared__ float smem[];
-    const int P = a.P;
-    float* th = smem;
-    float* mm = th + P;
-    float* vv = mm + P;
-    float* psl = vv + P;                               // r * penalty slope of CP angles
-    float2* cs = reinterpret_cast<float2*>(psl + P);   // (cos, sin) per parameter
-    float* gw = reinterpret_cast<float*>(cs + P);      // [WPS][P] per-wave gradient slots
-    float* red = gw + (size_t)L::WPS * P;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = a.P, G = a.G;
+    const GenLds lds(P, G, L::WPS);
+    float4* rec = reinterpret_cast<float4*>(smem + lds.rec);
+    float* th = smem + lds.th;
+    float* mm = smem + lds.mm;
+    float* vv = smem + lds.vv;
+    float* psl = smem + lds.psl;
+    float* gw = smem + lds.gw;
+    float* red = smem + lds.red;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,7 +499,21 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         diag[e] = (row == col);
     }
 
-    // owner threads: parameter j lives with thread j % THREADS
+    // static part of the gate records: opcode = kind | q0 << 4 | q1 << 8; CZ gates carry (cos, sin) = (-1, 0)
+    penalty_table_init(smem, a, tid);
+    for (int g = tid; g < G; g += L::THREADS) {
+        const int4 op = a.prog[g];
+        rec[g] = make_float4(op.x == OP_CZ ? -1.f : 1.f, 0.f, __int_as_float(op.x | (op.y << 4) | (op.z << 8)), 0.f);
+    }
+    lds_sync<L::WPS>();
+    // owner threads: parameter j lives with thread j % THREADS; pgate[j] = the gate that carries it
+    auto publish = [&](int j, float t) {
+        float sn, cn;
+        const bool cp = a.pkind[j];
+        sincosf(cp ? t : 0.5f * t, &sn, &cn);
+        float2* r = reinterpret_cast<float2*>(&rec[a.pgate[j]]);
+        *r = make_float2(cn, sn);
+    };
     for (int j = tid; j < P; j += L::THREADS) {
         const float t0 = init[j];
         th[j] = t0; mm[j] = 0.f; vv[j] = 0.f;
@@ -463,22 +521,25 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
             a.out_params[(s_idx * 2 + 0) * P + j] = t0;
             a.out_params[(s_idx * 2 + 1) * P + j] = t0;
         }
-        float sn, cn;
-        sincosf(a.pkind[j] ? t0 : 0.5f * t0, &sn, &cn);
-        cs[j] = make_float2(cn, sn);
+        publish(j, t0);
     }
-    __syncthreads();
+    lds_sync<L::WPS>();
 
     float best = 0.f, first = 0.f;
     const int iters = (a.mode == MODE_OPTIMIZE && a.T > 0) ? a.T : 1;
     for (int it = 0; it < iters; it++) {
+        const float2 bc = const_load_f2(a.bias, (a.mode == MODE_OPTIMIZE && a.T > 0) ? it : 0);
         // ---- forward: psi = G_{G-1} ... G_0
 #pragma unroll
         for (int e = 0; e < E; e++) { st.pr[e] = diag[e] ? 1.f : 0.f; st.pi[e] = 0.f; }
-        for (int g = 0; g < a.G; g++) {
-            const int4 op = a.prog[g];
-            const float2 c_s = cs[op.w];
-            op_forward<L>(op.x, op.y, op.z, c_s.x, c_s.y, st);
+        {
+            float4 rc = rec[0];
+            for (int g = 0; g < G; g++) {
+                const float4 rn = rec[g + 1 < G ? g + 1 : g];                 // prefetch the next record
+                const int code = __builtin_amdgcn_readfirstlane(__float_as_int(rc.z));
+                op_forward<L>(code & 15, (code >> 4) & 15, (code >> 8) & 15, rc.x, rc.y, st);
+                rc = rn;
+            }
         }
         if (a.mode == MODE_UNITARY) {
             const int d = NQ - a.n_actual, msk = (1 << d) - 1, N = 1 << a.n_actual;
@@ -501,7 +562,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
             for (int j = tid; j < P; j += L::THREADS) {
                 if (a.pkind[j]) {
                     float sl;
-                    acc[2] += penalty_value(a, th[j], sl);
+                    acc[2] += penalty_lds(smem, a.pen_kind, th[j], sl);
                     psl[j] = a.r * sl;
                 }
             }
@@ -541,46 +602,48 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
                 st.ci[e] = fmaf(fr, vi[e], fi * vr[e]);
             }
         }
-        for (int g = a.G - 1; g >= 0; g--) {
-            const int4 op = a.prog[g];
-            const float2 c_s = cs[op.w];
-            float d = op_backward<L>(op.x, op.y, op.z, c_s.x, c_s.y, st);
-            if (op.x != OP_CZ) {
+        {
+            float4 rc = rec[G - 1];
+            for (int g = G - 1; g >= 0; g--) {
+                const float4 rn = rec[g > 0 ? g - 1 : 0];
+                const int code = __builtin_amdgcn_readfirstlane(__float_as_int(rc.z));
+                float d = op_backward<L>(code & 15, (code >> 4) & 15, (code >> 8) & 15, rc.x, rc.y, st);
                 d = wave_sum(d);
-                if (lane == 0) gw[wave * P + op.w] = d;
+                if (lane == 0) gw[wave * G + g] = d;
+                rc = rn;
             }
         }
-        __syncthreads();
+        lds_sync<L::WPS>();
 
-        // ---- Adam (optax 0.1.1 scale_by_adam + scale(-lr)), owners only
+        // ---- gradient read-out / Adam (optax 0.1.1 scale_by_adam + scale(-lr)), owners only
         if (a.mode == MODE_LOSS_GRAD) {
             for (int j = tid; j < P; j += L::THREADS) {
+                const int pg = a.pgate[j];
                 float g = 0.f;
 #pragma unroll
-                for (int w = 0; w < L::WPS; w++) g += gw[w * P + j];
+                for (int w = 0; w < L::WPS; w++) g += gw[w * G + pg];
                 if (a.use_reg && a.pkind[j]) g += psl[j];
                 a.out_grad[s_idx * P + j] = g;
             }
             return;
         }
-        const float2 bc = a.bias[it];
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
         for (int j = tid; j < P; j += L::THREADS) {
+            const int pg = a.pgate[j];
             float g = 0.f;
 #pragma unroll
-            for (int w = 0; w < L::WPS; w++) g += gw[w * P + j];
+            for (int w = 0; w < L::WPS; w++) g += gw[w * G + pg];
             if (a.use_reg && a.pkind[j]) g += psl[j];
             if (frozen && frozen[j]) continue;
             const float m = fmaf(a.b1, mm[j], a.omb1 * g);
             const float v = fmaf(a.b2, vv[j], a.omb2 * (g * g));
             mm[j] = m; vv[j] = v;
-            const float mh = m / bc.x, vh = v / bc.y;
-            const float t = fmaf(-a.lr, mh / (sqrtf(vh) + a.eps), th[j]);
+            // hardware sqrt / rcp (1 ulp): the step error is ~1e-8, below the angle's own ulp
+            const float t = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[j]);
             th[j] = t;
-            float sn, cn;
-            sincosf(a.pkind[j] ? t : 0.5f * t, &sn, &cn);
-            cs[j] = make_float2(cn, sn);
+            publish(j, t);
         }
-        __syncthreads();
+        lds_sync<L::WPS>();
     }
 
     // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370);
@@ -592,7 +655,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
             const float t0 = a.out_params[(s_idx * 2 + 0) * P + j];
             const float t1 = a.out_params[(s_idx * 2 + 1) * P + j];
             float sl;
-            if (a.use_reg) { acc[0] += penalty_value(a, t0, sl); acc[1] += penalty_value(a, t1, sl); }
+            if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
             acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
         }
     }

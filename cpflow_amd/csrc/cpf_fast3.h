@@ -24,8 +24,7 @@ __host__ __device__ constexpr int rot_nr(int rot) { return rot & 15; }
 __host__ __device__ constexpr int rot_kind(int rot, int i) { return (rot >> (4 + 4 * i)) & 15; }
 
 struct Fast3Layout {                  // LDS float offsets
-    static constexpr int PEN_LO = 0;      // 8 lower break points of penalty pieces 1..8
-    static constexpr int PEN_SI = 8;      // 9 x (slope, intercept), padded to 20 floats
+    // floats [0, 28): penalty table (PEN_LO / PEN_SI of cpf_device.h)
     static constexpr int SURF_CS = 28;    // 9 x (c, s) = 18 floats, padded to 20
     static constexpr int BLK_CS = 48;     // + 16 * b : 7 x (c, s), [14] = pair code, [15] pad
     __host__ __device__ static constexpr int g_base(int K) { return BLK_CS + 16 * K; }
@@ -110,36 +109,11 @@ __device__ __forceinline__ void f3_block_bwd(State<L3>& st, const float (&r)[16]
     cp_apply<L3, Q0, Q1>(st.cr, st.ci, cc, -sc, st);
 }
 
-// penalty.py:44-71 from an LDS copy of the piece table: count the break points below x, then ONE
-// per-lane LDS read of that piece's (slope, intercept).  (Selecting among kernel-argument fields
-// made hipcc select the field ADDRESS and issue a global load from the kernarg segment per lane.)
-__device__ __forceinline__ float penalty_lds(const float* smem, int pen_kind, float ang, float& slope) {
-    if (pen_kind == 1) {
-        slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
-        return fabsf(ang);
-    }
-    const float x = floor_mod_2pi(ang);
-    const float4 l0 = *reinterpret_cast<const float4*>(smem + Fast3Layout::PEN_LO);
-    const float4 l1 = *reinterpret_cast<const float4*>(smem + Fast3Layout::PEN_LO + 4);
-    const int idx = (x > l0.x) + (x > l0.y) + (x > l0.z) + (x > l0.w) + (x > l1.x) + (x > l1.y) + (x > l1.z) + (x > l1.w);
-    const float2 si = *reinterpret_cast<const float2*>(smem + Fast3Layout::PEN_SI + 2 * idx);
-    slope = si.x;
-    return __fadd_rn(__fmul_rn(si.x, x), si.y);
-}
-
 __device__ __forceinline__ void load_rec(const float* p, float (&r)[16]) {
     const float4* q = reinterpret_cast<const float4*>(p);
     const float4 a = q[0], b = q[1], c = q[2], d = q[3];
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
     r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w; r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
-}
-
-// One wave per workgroup: a wave's LDS operations execute in order, so a write followed by a read
-// needs no s_barrier and no wait on outstanding GLOBAL stores (which __syncthreads() would add:
-// the best-angle / history stores are fire-and-forget).  Only the compiler must keep the order.
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
 }
 
 #define CPF_F3_PAIRS(M) M(0, 1) M(1, 0) M(0, 2) M(2, 0) M(1, 2) M(2, 1)
@@ -182,8 +156,7 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
     int cs_off[PPT], g_off[PPT], pj[PPT];
     bool valid[PPT], is_cp[PPT], frz[PPT];
-    if (lane < 8) smem[Fast3Layout::PEN_LO + lane] = a.pc[lane + 1].lo;
-    if (lane < 9) { smem[Fast3Layout::PEN_SI + 2 * lane] = a.pc[lane].slope; smem[Fast3Layout::PEN_SI + 2 * lane + 1] = a.pc[lane].icpt; }
+    penalty_table_init(smem, a, lane);
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
         const int o = lane + 64 * s;
@@ -365,7 +338,7 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
             reduce8_rows(d, smem + Fast3Layout::g_surf(K), lane, dst_lane);
             reduce8_rows(d2, smem + Fast3Layout::g_surf(K) + 32, lane, dst_lane);
         }
-        wave_lds_fence();
+        lds_sync<1>();
 
         // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner lanes
         const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
@@ -383,7 +356,7 @@ __global__ __launch_bounds__(64) void k_cp_fast3(const KArgs a) {
             }
             publish(s);
         }
-        wave_lds_fence();
+        lds_sync<1>();
     }
 
     // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164)

@@ -1,0 +1,130 @@
+// cpflow_amd: runtime specialisation of the layered kernel (cpf_layered.h) with hiprtc.
+//
+// A plan's circuit is fixed (qubits, rotation string, layer), so its block loop can be straight-line code.
+// The ahead-of-time build carries that specialisation only for the reference's two 3-qubit layers; every
+// other (n, waves per sample, rotation string, layer) is instantiated here on first use: the template
+// arguments are spliced into a one-line translation unit, compiled for gfx950 (~1 s), and the code object
+// is cached in memory and on disk ($CPF_JIT_CACHE or ~/.cache/cpflow_amd).  If anything fails the caller
+// falls back to the ahead-of-time generic kernel.  CPF_JIT=0 disables this path.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace cpf_jit {
+
+inline std::string lib_dir() {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&lib_dir), &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t k = p.find_last_of('/');
+        return k == std::string::npos ? std::string(".") : p.substr(0, k);
+    }
+    return ".";
+}
+
+inline std::string read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+inline uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+inline std::string cache_dir() {
+    const char* e = getenv("CPF_JIT_CACHE");
+    std::string d = e ? std::string(e) : std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/cpflow_amd";
+    std::string acc;
+    for (size_t i = 0; i <= d.size(); i++)
+        if (i == d.size() || d[i] == '/') { if (!acc.empty()) mkdir(acc.c_str(), 0755); if (i < d.size()) acc += '/'; }
+        else acc += d[i];
+    return d;
+}
+
+struct Kernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; };
+
+// key -> loaded kernel, per process (and per device: the key carries the device index)
+inline std::map<std::string, Kernel>& table() { static std::map<std::string, Kernel> t; return t; }
+inline std::mutex& table_mutex() { static std::mutex m; return m; }
+
+// Returns nullptr (and fills err) when the kernel cannot be produced.
+inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int ppt, const std::vector<int>& ud,
+                                 std::string* err) {
+    std::ostringstream name;
+    name << "cpf::k_cp_layered<" << nq << ", " << lw << ", " << rot_code << ", " << ppt;
+    for (int v : ud) name << ", " << v;
+    name << ">";
+    const std::string expr = name.str();
+    const std::string key = "dev" + std::to_string(device) + ":" + expr;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    auto it = table().find(key);
+    if (it != table().end()) return it->second.fn;
+
+    const std::string inc = lib_dir() + "/csrc";
+    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_fast3.h") + read_file(inc + "/cpf_layered.h");
+    if (hdrs.size() < 1000) { if (err) *err = "kernel headers not found under " + inc; return nullptr; }
+    const std::string src = "#include \"cpf_layered.h\"\nnamespace cpf { template __global__ void " + expr.substr(5) +
+                            "(const KArgs); }\n";
+    char hname[64];
+    snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src, fnv1a(hdrs)));
+    const std::string cpath = cache_dir() + "/" + hname + ".hsaco", npath = cache_dir() + "/" + hname + ".name";
+    std::string code = read_file(cpath), lowered = read_file(npath);
+    if (code.empty() || lowered.empty()) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "cpf_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+            if (err) *err = "hiprtcCreateProgram failed";
+            return nullptr;
+        }
+        hiprtcAddNameExpression(prog, expr.c_str());
+        const std::string i1 = "-I" + inc, i2 = "-I/opt/rocm/include";
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros",
+                              i1.c_str(), i2.c_str()};
+        const hiprtcResult r = hiprtcCompileProgram(prog, 7, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, '\0');
+            if (n) hiprtcGetProgramLog(prog, &log[0]);
+            if (err) *err = "hiprtc: " + log.substr(0, 400);
+            hiprtcDestroyProgram(&prog);
+            return nullptr;
+        }
+        size_t n = 0;
+        hiprtcGetCodeSize(prog, &n);
+        code.assign(n, '\0');
+        hiprtcGetCode(prog, &code[0]);
+        const char* low = nullptr;
+        hiprtcGetLoweredName(prog, expr.c_str(), &low);
+        lowered = low ? low : "";
+        hiprtcDestroyProgram(&prog);
+        if (lowered.empty()) { if (err) *err = "no lowered name"; return nullptr; }
+        std::ofstream(cpath + ".tmp", std::ios::binary) << code;
+        rename((cpath + ".tmp").c_str(), cpath.c_str());
+        std::ofstream(npath) << lowered;
+    }
+    Kernel k;
+    if (hipModuleLoadData(&k.module, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&k.fn, k.module, lowered.c_str()) != hipSuccess) {
+        if (err) *err = "hipModuleLoadData / hipModuleGetFunction failed for " + expr;
+        table()[key] = Kernel{};          // do not retry every launch
+        return nullptr;
+    }
+    table()[key] = k;
+    return k.fn;
+}
+
+}  // namespace cpf_jit

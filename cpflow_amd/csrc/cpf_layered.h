@@ -1,0 +1,363 @@
+// cpflow_amd: the layer-specialised persistent kernel, any n <= 6, 1 or 4 waves per sample.
+//
+// Generalisation of the 3-qubit kernel (cpf_fast3.h) over the layout Lay<NQ, LW>: the connectivity
+// layer is a compile-time sequence of (up, dn) pairs, so the block loop is straight-line code per layer
+// (no per-gate or per-block dispatch), the (cos, sin) of a block arrive as one prefetched 64-byte LDS
+// record, the 7 gradient partials of a block are reduced together by the DPP reduce-scatter, and the
+// optimiser state lives in the owner threads' registers.
+//
+// The template is instantiated at plan creation through hiprtc (cpf_jit.h) for the plan's
+// (n, waves, rotation string, layer); the ahead-of-time kernels remain the fallback.
+// Requires n == NQ (2-qubit problems, which run embedded, use the generic kernel).
+#pragma once
+#include "cpf_fast3.h"
+
+namespace cpf {
+
+template <int... I> struct iseq {};
+template <int N, int... I> struct make_iseq : make_iseq<N - 1, N - 1, I...> {};
+template <int... I> struct make_iseq<0, I...> { using type = iseq<I...>; };
+template <int V> struct ic { static constexpr int value = V; };
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, iseq<I...>) { (f(ic<I>{}), ...); }
+
+template <int... UD> struct PairList { static constexpr int v[sizeof...(UD) > 0 ? sizeof...(UD) : 1] = {UD...}; };
+
+template <int NQ>
+struct LayeredLds {                                       // float offsets; [0, 28) = penalty table
+    static constexpr int SURF_F = ((6 * NQ + 3) / 4) * 4;           // surface (cos, sin) record
+    static constexpr int NBATCH = (3 * NQ + 7) / 8;                 // reduce8 batches of the surface gradients
+    static constexpr int SURF_CS = PEN_FLOATS;
+    static constexpr int BLK_CS = SURF_CS + SURF_F;                 // + 16 b
+    __host__ __device__ static constexpr int g_base(int K) { return BLK_CS + 16 * K; }
+    __host__ __device__ static constexpr int g_wave(int K) { return 32 * (NBATCH + K); }      // floats per wave
+    __host__ __device__ static constexpr int g_surf(int K, int w) { return g_base(K) + w * g_wave(K); }
+    __host__ __device__ static constexpr int g_blk(int K, int w, int b) { return g_surf(K, w) + 32 * NBATCH + 32 * b; }
+    __host__ __device__ static constexpr int red(int K, int wps) { return g_base(K) + wps * g_wave(K); }
+    __host__ __device__ static constexpr int total(int K, int wps) { return red(K, wps) + 8 * wps + 4; }
+};
+
+// With 16+ elements per thread a layer body is a basic block of ~10^4 instructions; left alone the
+// scheduler interleaves gates and drives the kernel into scratch (measured: 248 VGPRs + 464 B/lane,
+// 4x slower).  A scheduling fence after every gate keeps the live set at psi + C + one record.
+template <class L>
+__device__ __forceinline__ void gate_fence() {
+    if constexpr (L::E >= 16) __builtin_amdgcn_sched_barrier(0);
+}
+
+// one entangling block on the generic layout (same gate order as f3_block_fwd / f3_block_bwd)
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]) {
+    constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
+    constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
+    cp_apply<L, Q0, Q1>(st.pr, st.pi, r[2 * (NB - 1)], r[2 * (NB - 1) + 1], st);
+    gate_fence<L>();
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+        } else {
+            rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+        }
+    }
+}
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s) {
+    const float d = rot_grad<L, KIND, Q>(st);
+    gate_fence<L>();
+    rot_apply<L, KIND, Q>(st.pr, st.pi, c, -s, st);
+    gate_fence<L>();
+    rot_apply<L, KIND, Q>(st.cr, st.ci, c, -s, st);
+    gate_fence<L>();
+    return d;
+}
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16], float (&d)[8]) {
+    constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
+    constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = 0.f;
+#pragma unroll
+    for (int i = NR - 1; i >= 0; i--) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP>(st, r[4 * i], r[4 * i + 1]);
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP>(st, r[4 * i], r[4 * i + 1]);
+        } else {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
+        }
+    }
+    const float cc = r[2 * (NB - 1)], sc = r[2 * (NB - 1) + 1];
+    d[NB - 1] = cp_grad<L, Q0, Q1>(st);
+    cp_apply<L, Q0, Q1>(st.pr, st.pi, cc, -sc, st);
+    cp_apply<L, Q0, Q1>(st.cr, st.ci, cc, -sc, st);
+    gate_fence<L>();
+}
+
+// UD... = up0, dn0, up1, dn1, ...: the layer (topology.py:15-20: block b sits on pair b mod len)
+template <int NQ, int LW, int ROT, int PPT, int... UD>
+__global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
+    using L = Lay<NQ, LW>;
+    using Lds = LayeredLds<NQ>;
+    using PL = PairList<UD...>;
+    constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS;
+    constexpr int LL = sizeof...(UD) / 2;
+    constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
+    static_assert(LL >= 1 && NR >= 1 && NR <= 3, "layered kernel: 1..3 rotation letters, non-empty layer");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P, K = (P - NS) / NB;
+    const int64_t s_idx = blockIdx.x;
+    const float* init = a.init + s_idx * P;
+    const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
+    float* out_best = a.out_params + (s_idx * 2 + 1) * P;
+    float* red = smem + Lds::red(K, WPS);
+
+    State<L> st;
+#pragma unroll
+    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; }
+    const int col = L::col_index(lane, wave);
+    // the target stays in registers for small tiles; with 16+ elements per thread it is re-read from
+    // L2 once per step (2 x 8 E bytes per thread per ~1e5 cycles) to keep the kernel out of scratch
+    constexpr bool KEEP_V = (E <= 4);
+    float vr[KEEP_V ? E : 1], vi[KEEP_V ? E : 1];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if constexpr (KEEP_V) { const float2 t = a.target[L::row_index(lane, e) * L::D + col]; vr[e] = t.x; vi[e] = t.y; }
+    }
+    const int dst_lane = (lane & 7) * 4 + (lane >> 4);
+
+    // ---- owner state.  Owner slot o = tid + THREADS * s; the K CP angles come first.
+    float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
+    int cs_off[PPT], g_off[PPT], pj[PPT];
+    bool valid[PPT], is_cp[PPT], frz[PPT];
+    penalty_table_init(smem, a, tid);
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        const int o = tid + THREADS * s;
+        valid[s] = o < P;
+        int j = 0;
+        if (valid[s]) {
+            if (o < K) j = NS + NB * o + NB - 1;
+            else if (o - K < NS) j = o - K;
+            else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+        }
+        pj[s] = j;
+        is_cp[s] = valid[s] && a.pkind[j];
+        frz[s] = valid[s] && frozen && frozen[j];
+        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
+        else {
+            const int b = (j - NS) / NB, k = (j - NS) % NB;
+            cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
+        }
+        th[s] = valid[s] ? init[j] : 0.f;
+        mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
+        if (valid[s]) { a.out_params[(s_idx * 2) * P + j] = th[s]; out_best[j] = th[s]; }
+    }
+    for (int b = tid; b < K; b += THREADS) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
+    auto publish = [&](int s) __attribute__((always_inline)) {
+        float sn, cn;
+        sincosf(is_cp[s] ? th[s] : 0.5f * th[s], &sn, &cn);
+        if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
+        if (a.use_reg && (K > THREADS * s) && is_cp[s]) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
+    };
+    lds_sync<WPS>();
+#pragma unroll
+    for (int s = 0; s < PPT; s++) publish(s);
+    lds_sync<WPS>();
+
+    float best = 0.f, first = 0.f;
+    const int iters = a.T > 0 ? a.T : 1;
+    for (int it = 0; it < iters; it++) {
+        const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
+        // ================= forward
+#pragma unroll
+        for (int e = 0; e < E; e++) { st.pr[e] = (L::row_index(lane, e) == col) ? 1.f : 0.f; st.pi[e] = 0.f; }
+        {
+            float sr[Lds::SURF_F];
+#pragma unroll
+            for (int i = 0; i < Lds::SURF_F / 4; i++) {
+                const float4 v = reinterpret_cast<const float4*>(smem + Lds::SURF_CS)[i];
+                sr[4 * i] = v.x; sr[4 * i + 1] = v.y; sr[4 * i + 2] = v.z; sr[4 * i + 3] = v.w;
+            }
+            static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
+                constexpr int Q = decltype(qq)::value;
+                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q], sr[6 * Q + 1], st);
+                rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
+                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
+            }, typename make_iseq<NQ>::type{});
+        }
+        if (K > 0) {
+            float rc[16];
+            load_rec(smem + Lds::BLK_CS, rc);
+            int b = 0;
+            while (b < K) {
+                static_for([&](auto ii) __attribute__((always_inline)) {
+                    constexpr int I = decltype(ii)::value;
+                    if (b < K) {
+                        if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
+                            load_rec(smem + Lds::BLK_CS + 16 * b, rc);
+                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc);
+                        } else {
+                            float rn[16];
+                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rn);      // prefetch next record
+                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc);
+#pragma unroll
+                            for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                        }
+                        b++;
+                    }
+                }, typename make_iseq<LL>::type{});
+            }
+        }
+        // ================= loss, penalty, best tracking
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            float2 t;
+            if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
+            acc[0] = fmaf(st.pr[e], t.x, acc[0]); acc[0] = fmaf(st.pi[e], t.y, acc[0]);
+            acc[1] = fmaf(st.pi[e], t.x, acc[1]); acc[1] = fmaf(-st.pr[e], t.y, acc[1]);
+        }
+        if (a.use_reg) {
+#pragma unroll
+            for (int s = 0; s < PPT; s++) acc[2] += pval[s];
+        }
+        block_sum<L, 3>(acc, red, wave, lane);
+        const float tr = acc[0], ti = acc[1];
+        const float reg = a.use_reg ? a.r * acc[2] : 0.f;
+        const float ab = sqrtf(fmaf(tr, tr, ti * ti));
+        const float loss = 1.f - ab * ab * a.inv_dim2;
+        const float regloss = loss + reg;
+        bool improved = false;
+        if (it == 0) { first = regloss; best = regloss; }
+        else if (regloss < best) { best = regloss; improved = true; }
+        if (improved) {
+#pragma unroll
+            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+        }
+        if (a.hist_params) {
+#pragma unroll
+            for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + pj[s]] = th[s];
+            if (tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
+        }
+        if (a.T == 0) break;
+
+        // ================= backward sweep
+        {
+            const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                float2 t;
+                if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
+                st.cr[e] = fmaf(fr, t.x, -fi * t.y);
+                st.ci[e] = fmaf(fr, t.y, fi * t.x);
+            }
+        }
+        float* gslab = smem + Lds::g_surf(K, wave);
+        if (K > 0) {
+            float rc[16], d[8];
+            load_rec(smem + Lds::BLK_CS + 16 * (K - 1), rc);
+            int b = K - 1;
+            auto step = [&](auto ii) __attribute__((always_inline)) {
+                constexpr int I = decltype(ii)::value;
+                if constexpr (E >= 16) {
+                    load_rec(smem + Lds::BLK_CS + 16 * b, rc);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc, d);
+                    reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
+                    gate_fence<L>();
+                } else {
+                    float rn[16];
+                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rn);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc, d);
+                    reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                }
+                b--;
+            };
+            const int rem = K % LL;        // the truncated last layer first, then full layers, pairs in reverse
+            static_for([&](auto ii) __attribute__((always_inline)) { constexpr int I = LL - 1 - decltype(ii)::value; if (I < rem) step(ic<I>{}); },
+                       typename make_iseq<LL>::type{});
+            while (b >= 0)
+                static_for([&](auto ii) __attribute__((always_inline)) { step(ic<LL - 1 - decltype(ii)::value>{}); }, typename make_iseq<LL>::type{});
+        }
+        {
+            float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
+#pragma unroll
+            for (int i = 0; i < Lds::SURF_F / 4; i++) {
+                const float4 v = reinterpret_cast<const float4*>(smem + Lds::SURF_CS)[i];
+                sr[4 * i] = v.x; sr[4 * i + 1] = v.y; sr[4 * i + 2] = v.z; sr[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8 * Lds::NBATCH; k++) ds[k] = 0.f;
+            static_for([&](auto qq) __attribute__((always_inline)) {
+                constexpr int Q = NQ - 1 - decltype(qq)::value;
+                ds[3 * Q + 2] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q + 4], sr[6 * Q + 5]);
+                ds[3 * Q + 1] = lay_rot_bwd<L, OP_RX, Q>(st, sr[6 * Q + 2], sr[6 * Q + 3]);
+                ds[3 * Q + 0] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q], sr[6 * Q + 1]);
+            }, typename make_iseq<NQ>::type{});
+#pragma unroll
+            for (int bt = 0; bt < Lds::NBATCH; bt++) {
+                float d8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d8[k] = ds[8 * bt + k];
+                reduce8_rows(d8, gslab + 32 * bt, lane, dst_lane);
+            }
+        }
+        lds_sync<WPS>();
+
+        // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            float g = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPS; w++) {
+                const float4 gp = *reinterpret_cast<const float4*>(smem + Lds::g_surf(K, w) + g_off[s]);
+                g += (gp.x + gp.y) + (gp.z + gp.w);
+            }
+            if (a.use_reg && is_cp[s]) g += psl[s];
+            if (valid[s] && !frz[s]) {
+                const float m = fmaf(a.b1, mm[s], a.omb1 * g);
+                const float v = fmaf(a.b2, vv[s], a.omb2 * (g * g));
+                mm[s] = m; vv[s] = v;
+                th[s] = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[s]);
+            }
+            publish(s);
+        }
+        lds_sync<WPS>();
+    }
+
+    // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164)
+    const int bi = (best < first) ? 1 : 0;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        if (is_cp[s]) {
+            const int j = pj[s];
+            const float t0 = a.out_params[(s_idx * 2) * P + j], t1 = out_best[j];
+            float sl;
+            if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
+            acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
+        }
+    }
+    block_sum<L, 3>(acc, red, wave, lane);
+    if (tid == 0) {
+        const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
+        const float l0 = first - reg0, l1 = best - reg1;
+        a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
+        a.out_reg[s_idx * 2 + 0] = reg0;      a.out_reg[s_idx * 2 + 1] = reg1;
+        a.out_loss[s_idx * 2 + 0] = l0;       a.out_loss[s_idx * 2 + 1] = l1;
+        a.out_cz[s_idx] = (int32_t)acc[2];
+        a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
+    }
+}
+
+}  // namespace cpf

@@ -14,6 +14,8 @@
 #include "../../include/cpflow_amd.h"
 #include "cpf_device.h"
 #include "cpf_fast3.h"
+#include "cpf_layered.h"
+#include "cpf_jit.h"
 
 namespace {
 
@@ -49,10 +51,14 @@ struct cpf_plan {
     int entangler = 0;
     std::string rot;
     int layer_code = 0;              // packed (up, dn) sequence when the placements cycle through <= 3 pairs
+    std::vector<int> layer_ud;       // (up, dn, up, dn, ...) of the shortest period of the placements
+    bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
+    std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
+    std::string variant;             // kernel variant of the last launch
     bool force_generic = false;      // CPF_FORCE_GENERIC=1: always use the generic per-gate kernel (A/B testing)
     std::vector<uint8_t> h_pkind;
     std::vector<int4> h_prog;
-    DevBuf d_prog, d_target, d_pkind, d_bias;
+    DevBuf d_prog, d_target, d_pkind, d_pgate, d_bias;
     cpf::KArgs base{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -108,7 +114,7 @@ int validate(const cpf_problem* pb) {
 template <int NQ, int LW>
 int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     using L = cpf::Lay<NQ, LW>;
-    const size_t lds = cpf::lds_floats(a.P, L::WPS) * sizeof(float);
+    const size_t lds = cpf::lds_floats(a.P, a.G, L::WPS) * sizeof(float);
     if (lds > 160 * 1024) return fail(-20, "P=%d needs %zu B of LDS (> 160 KiB)", a.P, lds);
     if (lds > 64 * 1024)
         CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_template<NQ, LW>),
@@ -138,7 +144,11 @@ int launch_fast3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hip
 
 // 3-qubit CP templates with a rotation string the specialised kernel is instantiated for
 // (and few enough angles to keep the optimiser state in registers) take the fast path.
-bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc, bool static_layers_only) {
+    { const char* e = getenv("CPF_NO_FAST3"); if (e && e[0] == '1') return false; }      // A/B: force the layered kernel
+    if (static_layers_only && plan->layer_code != cpf::layer_pack(2, 0, 1, 1, 2, 0, 0) &&
+        plan->layer_code != cpf::layer_pack(3, 0, 1, 0, 2, 1, 2))
+        return false;
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
         plan->entangler != CPF_ENTANGLER_CP || plan->K > 512)
         return false;
@@ -152,18 +162,67 @@ bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t
     return true;
 }
 
+// Runtime-specialised layered kernel (cpf_layered.h through hiprtc).  lw = log2(waves per sample).
+bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
+    plan->jit_note.clear();
+    if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE) return false;
+    if (plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP || plan->K < 1) return false;
+    if (plan->n_rot < 1 || plan->n_rot > 3 || plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
+    const int threads = 64 << lw, ppt = (a.P + threads - 1) / threads;
+    if (ppt > 12) { plan->jit_note = "too many angles per thread"; return false; }
+    int kinds[3] = {0, 0, 0};
+    for (int i = 0; i < plan->n_rot; i++) kinds[i] = plan->rot[i] == 'x' ? cpf::OP_RX : (plan->rot[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
+    const int rot_code = cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]);
+    size_t lds = 0;
+    switch (plan->NQ) {
+        case 3: lds = cpf::LayeredLds<3>::total(plan->K, 1 << lw); break;
+        case 4: lds = cpf::LayeredLds<4>::total(plan->K, 1 << lw); break;
+        case 5: lds = cpf::LayeredLds<5>::total(plan->K, 1 << lw); break;
+        case 6: lds = cpf::LayeredLds<6>::total(plan->K, 1 << lw); break;
+        default: return false;
+    }
+    lds *= sizeof(float);
+    if (lds > 64 * 1024) { plan->jit_note = "LDS footprint above 64 KiB"; return false; }
+    std::string err;
+    hipFunction_t fn = cpf_jit::get_layered(plan->device, plan->NQ, lw, rot_code, ppt, plan->layer_ud, &err);
+    if (!fn) { plan->jit_note = err; return false; }
+    cpf::KArgs args = a;
+    void* params[] = {&args};
+    const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
+    if (e != hipSuccess) { *rc = fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e)); return true; }
+    *rc = 0;
+    return true;
+}
+
 // Variant choice: one workgroup per sample; more waves per sample when there are too few
 // samples to fill 256 CUs x 4 SIMDs and the matrix is large enough to split by columns.
-int launch(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+    cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
     if (S <= 0) return 0;
     if (S > 0x7fffffffLL) return fail(-21, "num_samples too large");
     int rc = 0;
-    if (try_fast3(plan, a, S, stream, &rc)) return rc;
+    // 1. ahead-of-time 3-qubit kernel for the reference's own layers; 2. runtime-specialised layered kernel;
+    // 3. 3-qubit kernel with per-block dispatch; 4. generic per-gate kernel
+    if (try_fast3(plan, a, S, stream, &rc, true)) { plan->variant = "fast3/aot"; return rc; }
     const int64_t simds = (int64_t)plan->num_cu * 4;
+    // waves per sample: 1 when there are enough samples to fill the SIMDs, else 4 (columns split over waves)
+    int lw = 0;
+    // measured on MI355X: n=4 S=2048: 1 wave 9.9 ms vs 4 waves 17.0 ms; n=5 S=1000: 1 wave 22.4 ms vs 4 waves 29.6 ms
+    switch (plan->NQ) {
+        case 4: lw = (S >= simds) ? 0 : 2; break;
+        case 5: lw = (2 * S >= simds) ? 0 : 2; break;
+        case 6: lw = 2; break;
+        default: lw = 0;
+    }
+    { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
+    if (plan->NQ == 6) lw = 2;
+    if (try_layered_jit(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1"); return rc; }
+    if (try_fast3(plan, a, S, stream, &rc, false)) { plan->variant = "fast3/aot dynamic-layer"; return rc; }
+    plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
     switch (plan->NQ) {
         case 3: return launch_variant<3, 0>(a, S, stream);
-        case 4: return (S >= 2 * simds) ? launch_variant<4, 0>(a, S, stream) : launch_variant<4, 2>(a, S, stream);
-        case 5: return (S >= 4 * simds) ? launch_variant<5, 0>(a, S, stream) : launch_variant<5, 2>(a, S, stream);
+        case 4: return lw == 0 ? launch_variant<4, 0>(a, S, stream) : launch_variant<4, 2>(a, S, stream);
+        case 5: return lw == 0 ? launch_variant<5, 0>(a, S, stream) : launch_variant<5, 2>(a, S, stream);
         case 6: return launch_variant<6, 2>(a, S, stream);
         default: return fail(-2, "unsupported kernel width %d", plan->NQ);
     }
@@ -196,6 +255,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     pl->T = pb->num_iterations;
     pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
     { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
+    { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
     const int n = pl->n, NQ = pl->NQ, N = 1 << n, D = 1 << NQ, P = pl->P;
 
@@ -224,6 +284,17 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
         }
     }
     pl->G = (int)prog.size();
+    std::vector<int32_t> pgate((size_t)P, 0);
+    for (int g = 0; g < pl->G; g++)
+        if (prog[g].x != cpf::OP_CZ) pgate[prog[g].w] = g;
+    // shortest period of the placement sequence = the layer the specialised kernels are built around
+    for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
+        bool periodic = true;
+        for (int b = L; b < pl->K && periodic; b++)
+            periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
+                       pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
+        if (periodic) pl->layer_ud.assign(pb->placements, pb->placements + 2 * L);
+    }
     // periodic placements with period <= 3 -> compile-time layer code for the 3-qubit kernel
     pl->layer_code = 0;
     if (n == 3 && pl->K > 0) {
@@ -263,6 +334,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     up(pl->d_prog, prog.data(), prog.size() * sizeof(int4));
     up(pl->d_target, tgt.data(), tgt.size() * sizeof(float2));
     up(pl->d_pkind, pl->h_pkind.data(), (size_t)P);
+    up(pl->d_pgate, pgate.data(), pgate.size() * sizeof(int32_t));
     up(pl->d_bias, bias.data(), bias.size() * sizeof(float2));
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
@@ -279,6 +351,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     a.n_actual = n;
     a.target = pl->d_target.as<float2>();
     a.pkind = pl->d_pkind.as<uint8_t>();
+    a.pgate = pl->d_pgate.as<int32_t>();
     a.bias = pl->d_bias.as<float2>();
     build_pieces(pb->penalty, a.pc);
     a.pen_kind = pb->penalty.kind;
@@ -351,6 +424,12 @@ int32_t cpf_optimize_device(const cpf_plan* plan_c, int64_t S, const float* d_in
     if (int rc = launch(plan, a, S, (hipStream_t)stream)) return rc;
     CPF_HIP(hipEventRecord(plan->ev1, (hipStream_t)stream));
     plan->timed = true;
+    return 0;
+}
+
+int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size) {
+    if (!plan || !buf || !size) return fail(-1, "NULL argument");
+    snprintf(buf, size, "%s", plan->variant.c_str());
     return 0;
 }
 

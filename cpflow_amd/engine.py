@@ -160,6 +160,12 @@ class TemplateEngine:
         times = [a.elapsed_time(b) for a, b in self.event_log]
         return sum(times) / len(times), times
 
+    def last_variant(self):
+        """Name of the kernel variant the last launch used (fast3/aot, layered/jit, generic/aot)."""
+        buf = C.create_string_buffer(512)
+        _ffi.check(self._lib.cpf_plan_last_variant(self._plan, buf, 512))
+        return buf.value.decode()
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         _ffi.check(self._lib.cpf_plan_last_kernel_ms(self._plan, C.byref(ms)))

@@ -105,3 +105,42 @@ def test_short_adam_trajectory_matches_fp32_oracle(layer, K, rot):
     for s in range(S):
         assert any((best[s] == hp[s, t]).all() for t in range(T))
         assert out['regloss'].cpu().numpy()[s, 1] == hl[s].min()
+
+
+@pytest.mark.parametrize('layer,K,rot,lw', [
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', '0'), ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', '2'),
+    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', '0'), ([[1, 0], [2, 1], [0, 2]], 7, 'xz', '0'),
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', '2'), ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', '0'),
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', '2'), ([[0, 5], [2, 3], [4, 1]], 5, 'zx', '2'),
+])
+def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw, monkeypatch):
+    """The hiprtc-specialised layered kernel (cpf_layered.h), the ahead-of-time generic kernel and the
+    float64 oracle agree on short Adam runs (incl. frozen angles); 1 and 4 waves per sample."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 5)
+    T, S = 12, 5
+    orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.003)
+    init = orc.initial_angles(3, S)
+    frozen = np.zeros((S, orc.P), dtype=np.uint8)
+    frozen[1::2, ::5] = 1
+    monkeypatch.setenv('CPF_LW', lw)
+    outs = {}
+    for jit in ('1', '0'):
+        monkeypatch.setenv('CPF_JIT', jit)
+        eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
+        outs[jit] = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+        outs[jit + 'f'] = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
+        assert eng.last_variant().startswith('layered/jit' if jit == '1' else ('fast3/aot' if n == 3 else 'generic/aot')), eng.last_variant()
+        assert eng.last_variant().endswith('waves=' + ('4' if lw == '2' and n > 3 else '1')) or jit == '0'
+        eng.close()
+    ref = orc.run(init, np.float64, keep_history=True)
+    for jit in ('1', '0'):
+        assert np.abs(outs[jit]['history_regloss'] - ref['history_loss']).max() < 2e-5
+        assert np.abs(outs[jit]['history_params'] - ref['history_params']).max() < 2e-4
+        assert (outs[jit]['cz'] == ref['cz']).all()
+    assert np.abs(outs['1']['regloss'] - outs['0']['regloss']).max() < 2e-5
+    # frozen angles never move, the others do
+    for key in ('1f', '0f'):
+        p = outs[key]['params']
+        assert (p[:, 1][frozen == 1] == init[frozen == 1]).all()
+    assert np.abs(outs['1f']['regloss'] - outs['0f']['regloss']).max() < 2e-5

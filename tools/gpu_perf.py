@@ -31,4 +31,4 @@ for name in (sys.argv[1:] or ['cfg2']):
             out = eng.optimize(init); ms.append(eng.last_kernel_ms())
         ms = min(ms)
         print(f'{name} S={S} T={T} kernel {ms:.2f} ms  {S*T/ms*1e3:.3e} sample-steps/s  {eng.flops_per_sample_step*S*T/ms*1e3/1e12:.2f} TFLOP/s  '
-              f'passed {int(out["passed"].sum())} minCZ {int(out["cz"][out["passed"]].min()) if out["passed"].any() else -1}', flush=True)
+              f'[{eng.last_variant()}] passed {int(out["passed"].sum())} minCZ {int(out["cz"][out["passed"]].min()) if out["passed"].any() else -1}', flush=True)
