@@ -3,8 +3,9 @@
 // A plan's circuit is fixed (qubits, rotation string, layer), so its block loop can be straight-line code.
 // The ahead-of-time build carries that specialisation only for the reference's two 3-qubit layers; every
 // other (n, waves per sample, rotation string, layer) is instantiated here on first use: the template
-// arguments are spliced into a one-line translation unit, compiled for gfx950 (~1 s), and the code object
-// is cached in memory and on disk ($CPF_JIT_CACHE or ~/.cache/cpflow_amd).  If anything fails the caller
+// arguments are spliced into a three-line translation unit, compiled for gfx950 (1-6 s; hipcc --genco as a
+// child process, hiprtc as fallback), and the code object is cached in memory and on disk ($CPF_JIT_CACHE
+// or ~/.cache/cpflow_amd).  If anything fails the caller
 // falls back to the ahead-of-time generic kernel.  CPF_JIT=0 disables this path.
 #pragma once
 #include <dlfcn.h>
@@ -75,21 +76,49 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
     if (it != table().end()) return it->second.fn;
 
     const std::string inc = lib_dir() + "/csrc";
-    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_fast3.h") + read_file(inc + "/cpf_layered.h");
+    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_blocks.h") + read_file(inc + "/cpf_layered.h");
     if (hdrs.size() < 1000) { if (err) *err = "kernel headers not found under " + inc; return nullptr; }
-    const std::string src = "#include \"cpf_layered.h\"\nnamespace cpf { template __global__ void " + expr.substr(5) +
-                            "(const KArgs); }\n";
+    // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
+    std::ostringstream targs;
+    targs << nq << ", " << lw << ", " << rot_code << ", " << ppt;
+    for (int v : ud) targs << ", " << v;
+    const std::string src = "#include \"cpf_layered.h\"\nextern \"C\" __global__ __launch_bounds__(" +
+                            std::to_string(64 << lw) + ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    cpf::layered_body<" +
+                            targs.str() + ">(a);\n}\n";
+    // Backend: the offline compiler as a child process by default.  hiprtc builds the same source with the
+    // same flags, but on the MI355X boxes its code came out 2x slower (SGPR spills through v_writelane /
+    // v_readlane, 4477 vs 3536 instructions for the 3-qubit chain kernel: 20.6 ms vs 11.0 ms on config 2);
+    // it stays as the fallback when no hipcc is installed.  CPF_JIT_BACKEND=hiprtc|hipcc overrides.
+    const char* be = getenv("CPF_JIT_BACKEND");
+    const char* hipcc_env = getenv("HIPCC");
+    const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
+    struct stat st_;
+    const bool have_hipcc = stat(hipcc.c_str(), &st_) == 0;
+    const bool use_hipcc = be ? std::string(be) == "hipcc" : have_hipcc;
     char hname[64];
-    snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src, fnv1a(hdrs)));
-    const std::string cpath = cache_dir() + "/" + hname + ".hsaco", npath = cache_dir() + "/" + hname + ".name";
-    std::string code = read_file(cpath), lowered = read_file(npath);
-    if (code.empty() || lowered.empty()) {
+    snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src + (use_hipcc ? "hipcc" : "hiprtc"), fnv1a(hdrs)));
+    const std::string cpath = cache_dir() + "/" + hname + ".hsaco";
+    std::string code = read_file(cpath);
+    const std::string lowered = "cpf_jit_kernel";
+    if (code.empty() && use_hipcc) {
+        // offline compiler as a subprocess (same flags as the ahead-of-time build)
+        const std::string spath = cache_dir() + "/" + hname + ".hip";
+        std::ofstream(spath) << src;
+        const std::string cmd = hipcc + " --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-signed-zeros "
+                                "--genco -I" + inc + " -o " + cpath + ".tmp " + spath + " > " + cpath + ".log 2>&1";
+        if (system(cmd.c_str()) == 0) {
+            rename((cpath + ".tmp").c_str(), cpath.c_str());
+            code = read_file(cpath);
+        } else if (err) {
+            *err = "hipcc --genco failed, see " + cpath + ".log; ";
+        }
+    }
+    if (code.empty()) {
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, src.c_str(), "cpf_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             if (err) *err = "hiprtcCreateProgram failed";
             return nullptr;
         }
-        hiprtcAddNameExpression(prog, expr.c_str());
         const std::string i1 = "-I" + inc, i2 = "-I/opt/rocm/include";
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros",
                               i1.c_str(), i2.c_str()};
@@ -107,14 +136,9 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
         hiprtcGetCodeSize(prog, &n);
         code.assign(n, '\0');
         hiprtcGetCode(prog, &code[0]);
-        const char* low = nullptr;
-        hiprtcGetLoweredName(prog, expr.c_str(), &low);
-        lowered = low ? low : "";
         hiprtcDestroyProgram(&prog);
-        if (lowered.empty()) { if (err) *err = "no lowered name"; return nullptr; }
         std::ofstream(cpath + ".tmp", std::ios::binary) << code;
         rename((cpath + ".tmp").c_str(), cpath.c_str());
-        std::ofstream(npath) << lowered;
     }
     Kernel k;
     if (hipModuleLoadData(&k.module, code.data()) != hipSuccess ||

@@ -1,16 +1,16 @@
 // cpflow_amd: the layer-specialised persistent kernel, any n <= 6, 1 or 4 waves per sample.
 //
-// Generalisation of the 3-qubit kernel (cpf_fast3.h) over the layout Lay<NQ, LW>: the connectivity
+// Layout Lay<NQ, LW> (cpf_device.h); the connectivity
 // layer is a compile-time sequence of (up, dn) pairs, so the block loop is straight-line code per layer
 // (no per-gate or per-block dispatch), the (cos, sin) of a block arrive as one prefetched 64-byte LDS
 // record, the 7 gradient partials of a block are reduced together by the DPP reduce-scatter, and the
 // optimiser state lives in the owner threads' registers.
 //
-// The template is instantiated at plan creation through hiprtc (cpf_jit.h) for the plan's
-// (n, waves, rotation string, layer); the ahead-of-time kernels remain the fallback.
+// Instantiated ahead of time for the reference's two 3-qubit layers (chain, all-to-all) and at run time
+// (cpf_jit.h) for every other (n, waves, rotation string, layer); the generic kernel is the fallback.
 // Requires n == NQ (2-qubit problems, which run embedded, use the generic kernel).
 #pragma once
-#include "cpf_fast3.h"
+#include "cpf_blocks.h"
 
 namespace cpf {
 
@@ -45,7 +45,7 @@ __device__ __forceinline__ void gate_fence() {
     if constexpr (L::E >= 16) __builtin_amdgcn_sched_barrier(0);
 }
 
-// one entangling block on the generic layout (same gate order as f3_block_fwd / f3_block_bwd)
+// one entangling block on the generic layout (CP first, then R_g(up) R_g(dn) per letter; main.py:69-82)
 template <class L, int UP, int DN, int ROT>
 __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]) {
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
@@ -101,12 +101,13 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
 
 // UD... = up0, dn0, up1, dn1, ...: the layer (topology.py:15-20: block b sits on pair b mod len)
 template <int NQ, int LW, int ROT, int PPT, int... UD>
-__global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
+__device__ __forceinline__ void layered_body(const KArgs& a) {
     using L = Lay<NQ, LW>;
     using Lds = LayeredLds<NQ>;
     using PL = PairList<UD...>;
     constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS;
     constexpr int LL = sizeof...(UD) / 2;
+    constexpr int UNR = (LL % 2 == 0) ? LL : 2 * LL;      // blocks per unrolled loop body (even, for buffer parity)
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
     static_assert(LL >= 1 && NR >= 1 && NR <= 3, "layered kernel: 1..3 rotation letters, non-empty layer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -194,26 +195,28 @@ __global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
             }, typename make_iseq<NQ>::type{});
         }
         if (K > 0) {
-            float rc[16];
-            load_rec(smem + Lds::BLK_CS, rc);
+            // two record buffers used alternately with a compile-time parity (no register copies):
+            // the body covers UNR blocks = one layer, or two layers when the layer length is odd
+            float ra[16], rb[16];
             int b = 0;
+            if constexpr (E < 16) load_rec(smem + Lds::BLK_CS, ra);
             while (b < K) {
-                static_for([&](auto ii) __attribute__((always_inline)) {
-                    constexpr int I = decltype(ii)::value;
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jj)::value, I = J % LL;
                     if (b < K) {
                         if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
-                            load_rec(smem + Lds::BLK_CS + 16 * b, rc);
-                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc);
+                            load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
+                        } else if constexpr ((J & 1) == 0) {
+                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rb);      // prefetch next record
+                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
                         } else {
-                            float rn[16];
-                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rn);      // prefetch next record
-                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc);
-#pragma unroll
-                            for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), ra);
+                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb);
                         }
                         b++;
                     }
-                }, typename make_iseq<LL>::type{});
+                }, typename make_iseq<UNR>::type{});
             }
         }
         // ================= loss, penalty, best tracking
@@ -262,31 +265,41 @@ __global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
         }
         float* gslab = smem + Lds::g_surf(K, wave);
         if (K > 0) {
-            float rc[16], d[8];
-            load_rec(smem + Lds::BLK_CS + 16 * (K - 1), rc);
+            float ra[16], rb[16], d[8];
             int b = K - 1;
-            auto step = [&](auto ii) __attribute__((always_inline)) {
-                constexpr int I = decltype(ii)::value;
-                if constexpr (E >= 16) {
-                    load_rec(smem + Lds::BLK_CS + 16 * b, rc);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc, d);
+            // the truncated last layer first (blocks on pairs K % LL - 1 .. 0, no prefetch), then full layers
+            const int rem = K % LL;
+            static_for([&](auto ii) __attribute__((always_inline)) {
+                constexpr int I = LL - 1 - decltype(ii)::value;
+                if (I < rem) {
+                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
                     reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
                     gate_fence<L>();
-                } else {
-                    float rn[16];
-                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rn);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rc, d);
-                    reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) rc[i] = rn[i];
+                    b--;
                 }
-                b--;
-            };
-            const int rem = K % LL;        // the truncated last layer first, then full layers, pairs in reverse
-            static_for([&](auto ii) __attribute__((always_inline)) { constexpr int I = LL - 1 - decltype(ii)::value; if (I < rem) step(ic<I>{}); },
-                       typename make_iseq<LL>::type{});
-            while (b >= 0)
-                static_for([&](auto ii) __attribute__((always_inline)) { step(ic<LL - 1 - decltype(ii)::value>{}); }, typename make_iseq<LL>::type{});
+            }, typename make_iseq<LL>::type{});
+            if constexpr (E < 16) { if (b >= 0) load_rec(smem + Lds::BLK_CS + 16 * b, ra); }
+            while (b >= 0) {
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jj)::value, I = LL - 1 - (J % LL);
+                    if (b >= 0) {
+                        if constexpr (E >= 16) {
+                            load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
+                        } else if constexpr ((J & 1) == 0) {
+                            load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
+                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
+                        } else {
+                            load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), ra);
+                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb, d);
+                        }
+                        reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
+                        gate_fence<L>();
+                        b--;
+                    }
+                }, typename make_iseq<UNR>::type{});
+            }
         }
         {
             float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
@@ -358,6 +371,11 @@ __global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
         a.out_cz[s_idx] = (int32_t)acc[2];
         a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
     }
+}
+
+template <int NQ, int LW, int ROT, int PPT, int... UD>
+__global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
+    layered_body<NQ, LW, ROT, PPT, UD...>(a);
 }
 
 }  // namespace cpf

@@ -13,7 +13,7 @@
 
 #include "../../include/cpflow_amd.h"
 #include "cpf_device.h"
-#include "cpf_fast3.h"
+#include "cpf_blocks.h"
 #include "cpf_layered.h"
 #include "cpf_jit.h"
 
@@ -50,7 +50,6 @@ struct cpf_plan {
     int n = 0, K = 0, n_rot = 0, nb = 0, P = 0, G = 0, T = 0, NQ = 0;
     int entangler = 0;
     std::string rot;
-    int layer_code = 0;              // packed (up, dn) sequence when the placements cycle through <= 3 pairs
     std::vector<int> layer_ud;       // (up, dn, up, dn, ...) of the shortest period of the placements
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
@@ -124,42 +123,35 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     return 0;
 }
 
-template <int ROT, int PPT, int LAYER>
-int launch_fast3(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
-    const size_t lds = (size_t)cpf::Fast3Layout::total(K) * sizeof(float);
-    hipLaunchKernelGGL((cpf::k_cp_fast3<ROT, PPT, LAYER>), dim3((unsigned)S), dim3(64), lds, stream, a);
+// Ahead-of-time instances of the layered kernel: 3 qubits, the reference's two layer constructors
+// (chain_layer(3), connected_layer(3); topology.py:7-12), 'xyz' / 'xz', optimiser state for <= 128 / 256 angles.
+template <int ROT, int PPT, int... UD>
+int launch_layered3(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    const size_t lds = (size_t)cpf::LayeredLds<3>::total(K, 1) * sizeof(float);
+    hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, UD...>), dim3((unsigned)S), dim3(64), lds, stream, a);
     CPF_HIP(hipGetLastError());
     return 0;
 }
-
 template <int ROT, int PPT>
-int launch_fast3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
-    // the two layer constructors of the reference for 3 qubits (topology.py:7-12) get straight-line code
-    constexpr int CHAIN = cpf::layer_pack(2, 0, 1, 1, 2, 0, 0);
-    constexpr int CONN = cpf::layer_pack(3, 0, 1, 0, 2, 1, 2);
-    if (plan->layer_code == CHAIN) return launch_fast3<ROT, PPT, CHAIN>(a, plan->K, S, stream);
-    if (plan->layer_code == CONN) return launch_fast3<ROT, PPT, CONN>(a, plan->K, S, stream);
-    return launch_fast3<ROT, PPT, 0>(a, plan->K, S, stream);
+bool launch_layered3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    const std::vector<int>& ud = plan->layer_ud;
+    if (ud == std::vector<int>{0, 1, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 1, 2>(a, plan->K, S, stream); return true; }
+    if (ud == std::vector<int>{0, 1, 0, 2, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 0, 2, 1, 2>(a, plan->K, S, stream); return true; }
+    return false;
 }
-
-// 3-qubit CP templates with a rotation string the specialised kernel is instantiated for
-// (and few enough angles to keep the optimiser state in registers) take the fast path.
-bool try_fast3(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc, bool static_layers_only) {
-    { const char* e = getenv("CPF_NO_FAST3"); if (e && e[0] == '1') return false; }      // A/B: force the layered kernel
-    if (static_layers_only && plan->layer_code != cpf::layer_pack(2, 0, 1, 1, 2, 0, 0) &&
-        plan->layer_code != cpf::layer_pack(3, 0, 1, 0, 2, 1, 2))
-        return false;
+bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    { const char* e = getenv("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
-        plan->entangler != CPF_ENTANGLER_CP || plan->K > 512)
+        plan->entangler != CPF_ENTANGLER_CP || plan->K < 1)
         return false;
-    const int ppt = a.P <= 128 ? 2 : (a.P <= 256 ? 4 : 0);
-    if (!ppt) return false;
+    const int ppt = (a.P + 63) / 64;
     constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
     constexpr int XZ = cpf::rot_pack(2, cpf::OP_RX, cpf::OP_RZ, 0);
-    if (plan->rot == "xyz") *rc = ppt == 2 ? launch_fast3_layer<XYZ, 2>(plan, a, S, stream) : launch_fast3_layer<XYZ, 4>(plan, a, S, stream);
-    else if (plan->rot == "xz") *rc = ppt == 2 ? launch_fast3_layer<XZ, 2>(plan, a, S, stream) : launch_fast3_layer<XZ, 4>(plan, a, S, stream);
-    else return false;
-    return true;
+    if (plan->rot == "xyz" && ppt <= 2) return launch_layered3_layer<XYZ, 2>(plan, a, S, stream, rc);
+    if (plan->rot == "xyz" && ppt <= 4) return launch_layered3_layer<XYZ, 4>(plan, a, S, stream, rc);
+    if (plan->rot == "xz" && ppt <= 2) return launch_layered3_layer<XZ, 2>(plan, a, S, stream, rc);
+    if (plan->rot == "xz" && ppt <= 4) return launch_layered3_layer<XZ, 4>(plan, a, S, stream, rc);
+    return false;
 }
 
 // Runtime-specialised layered kernel (cpf_layered.h through hiprtc).  lw = log2(waves per sample).
@@ -201,9 +193,9 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     if (S <= 0) return 0;
     if (S > 0x7fffffffLL) return fail(-21, "num_samples too large");
     int rc = 0;
-    // 1. ahead-of-time 3-qubit kernel for the reference's own layers; 2. runtime-specialised layered kernel;
-    // 3. 3-qubit kernel with per-block dispatch; 4. generic per-gate kernel
-    if (try_fast3(plan, a, S, stream, &rc, true)) { plan->variant = "fast3/aot"; return rc; }
+    // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
+    // kernel; 3. generic per-gate kernel
+    if (try_layered3_aot(plan, a, S, stream, &rc)) { plan->variant = "layered/aot waves=1"; return rc; }
     const int64_t simds = (int64_t)plan->num_cu * 4;
     // waves per sample: 1 when there are enough samples to fill the SIMDs, else 4 (columns split over waves)
     int lw = 0;
@@ -217,7 +209,6 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1"); return rc; }
-    if (try_fast3(plan, a, S, stream, &rc, false)) { plan->variant = "fast3/aot dynamic-layer"; return rc; }
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
     switch (plan->NQ) {
         case 3: return launch_variant<3, 0>(a, S, stream);
@@ -295,21 +286,6 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
                        pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
         if (periodic) pl->layer_ud.assign(pb->placements, pb->placements + 2 * L);
     }
-    // periodic placements with period <= 3 -> compile-time layer code for the 3-qubit kernel
-    pl->layer_code = 0;
-    if (n == 3 && pl->K > 0) {
-        for (int L = 1; L <= 3 && !pl->layer_code; L++) {
-            bool periodic = true;
-            for (int b = L; b < pl->K && periodic; b++)
-                periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
-                           pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
-            if (!periodic) continue;
-            int pr[6] = {0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < L && i < pl->K; i++) { pr[2 * i] = pb->placements[2 * i]; pr[2 * i + 1] = pb->placements[2 * i + 1]; }
-            if (pl->K >= L) pl->layer_code = cpf::layer_pack(L, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5]);
-        }
-    }
-
     // ---- target, used as complex64, embedded as V (x) I when the kernel is wider than the problem
     std::vector<float2> tgt((size_t)D * D, make_float2(0.f, 0.f));
     const int d = NQ - n;

@@ -123,8 +123,8 @@ int32_t cpf_unitary_device(const cpf_plan* plan, int64_t num_samples, const floa
 /* Duration in ms of the last cpf_optimize_device kernel of this plan, measured with HIP events
  * on the launch stream (blocks until that kernel has finished). */
 int32_t cpf_plan_last_kernel_ms(cpf_plan* plan, float* out_ms);
-/* Which kernel the last launch on this plan used: "fast3/aot", "layered/jit waves=N" (runtime-specialised,
- * hiprtc) or "generic/aot waves=N (reason)". */
+/* Which kernel the last launch on this plan used: "layered/aot waves=1", "layered/jit waves=N" (runtime-specialised,
+ * built on first use) or "generic/aot waves=N (reason)". */
 int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
 
 /* ---- host-pointer convenience (what a ctypes binding of _generate_raw + _evaluate_raw

@@ -130,7 +130,7 @@ def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw
         eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
         outs[jit] = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
         outs[jit + 'f'] = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
-        assert eng.last_variant().startswith('layered/jit' if jit == '1' else ('fast3/aot' if n == 3 else 'generic/aot')), eng.last_variant()
+        assert eng.last_variant().startswith('layered/jit' if jit == '1' else 'generic/aot'), eng.last_variant()
         assert eng.last_variant().endswith('waves=' + ('4' if lw == '2' and n > 3 else '1')) or jit == '0'
         eng.close()
     ref = orc.run(init, np.float64, keep_history=True)
