@@ -144,3 +144,55 @@ def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw
         p = outs[key]['params']
         assert (p[:, 1][frozen == 1] == init[frozen == 1]).all()
     assert np.abs(outs['1f']['regloss'] - outs['0f']['regloss']).max() < 2e-5
+
+
+def test_edge_cases_match_oracle():
+    """Empty batch, single sample, zero iterations, one block, a layer longer than the template,
+    two qubits, more angles than one wave holds two per lane (K = 30), L1 penalty."""
+    rng = np.random.default_rng(2)
+    # S = 0
+    eng = _engine([[0, 1], [1, 2]], 4, np.eye(8), 'xyz', num_gd_iterations=5)
+    out = eng.optimize(np.zeros((0, eng.num_angles), dtype=np.float32))
+    assert out['params'].shape == (0, 2, eng.num_angles) and out['cz'].shape == (0,)
+    assert eng.initial_angles(1, 0).shape == (0, eng.num_angles)
+    cases = [
+        ([[0, 1], [1, 2]], 1, 'xyz', 7, 1, {}),                       # K < len(layer), S = 1
+        ([[0, 1], [0, 2], [1, 2]], 2, 'xz', 6, 3, {}),                # truncated first layer only
+        ([[0, 1], [1, 2]], 30, 'xyz', 4, 2, {}),                      # P = 219: four angles per lane
+        ([[0, 1]], 3, 'xyz', 6, 2, {}),                               # 2 qubits (embedded in the 3-qubit kernel)
+        ([[0, 1], [1, 2]], 5, 'xyz', 0, 2, {}),                       # zero iterations: evaluation only
+        ([[0, 1], [1, 2], [2, 3]], 7, 'zy', 5, 2, {'penalty': 'L1'}),
+        ([[0, 1], [1, 2]], 6, 'xyz', 6, 2, {'plato_0': 0.1, 'plato_1': 0.02, 'xmax': 1.3, 'ymax': 1.5}),
+    ]
+    for layer, K, rot, T, S, kw in cases:
+        n = max(max(p) for p in layer) + 1
+        target = _rand_unitary(n, 11)
+        orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.01, **kw)
+        eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.01, **kw)
+        init = orc.initial_angles(5, S)
+        ref = orc.run(init, np.float64)
+        out = {k: v.cpu().numpy() for k, v in eng.optimize(init).items()}
+        assert np.abs(out['regloss'] - ref['regloss']).max() < 2e-5, (layer, K, rot, T)
+        assert np.abs(out['reg'] - ref['reg']).max() < 1e-6
+        assert np.abs(out['loss'] - ref['loss']).max() < 2e-5
+        assert (out['cz'] == ref['cz']).all() and (out['passed'] == ref['passed']).all()
+        if T == 0:
+            assert (out['params'][:, 1] == init).all() and (out['regloss'][:, 0] == out['regloss'][:, 1]).all()
+
+
+def test_abi_errors_on_device():
+    """Invalid arguments come back as ValueError with the library's message; nothing is launched."""
+    from cpflow_amd.engine import TemplateEngine
+    with pytest.raises(ValueError, match='placement'):
+        TemplateEngine([[0, 0]], 2, np.eye(4), num_qubits=2)
+    with pytest.raises(ValueError, match='rotation'):
+        TemplateEngine([[0, 1]], 2, np.eye(4), 'xq')
+    with pytest.raises(TypeError, match="not implemented"):
+        TemplateEngine([[0, 1]], 2, np.eye(4), entangler='swap')
+    with pytest.raises(AssertionError, match='do not match'):
+        TemplateEngine([[0, 1], [1, 2]], 2, np.eye(4))
+    eng = TemplateEngine([[0, 1]], 2, np.eye(4))
+    with pytest.raises(AssertionError):
+        eng.optimize(np.zeros((2, eng.num_angles + 1), dtype=np.float32))
+    with pytest.raises(NotImplementedError):
+        eng.initial_angles(0, 4, cp_dist='normal')
