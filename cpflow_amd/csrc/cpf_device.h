@@ -671,6 +671,22 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ reg(theta) for arbitrary angle rows
+// r * sum_i R(theta_i * mask_i) (main.py:563-564), one thread per row: the recomputation
+// jit(vmap(vmap(regularization_func))) of optimization.py:365-367 for history rows.
+__global__ void k_reg_rows(const KArgs a, const float* theta, int64_t count, float* reg) {
+    __shared__ __attribute__((aligned(16))) float tab[PEN_FLOATS + 4];
+    penalty_table_init(tab, a, threadIdx.x);
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= count) return;
+    float acc = 0.f;
+    if (a.use_reg)
+        for (int j = 0; j < a.P; j++)
+            if (a.pkind[j]) { float sl; acc += penalty_lds(tab, a.pen_kind, theta[row * a.P + j], sl); }
+    reg[row] = a.use_reg ? a.r * acc : 0.f;
+}
+
 // ------------------------------------------------------------------ initial angles (jax threefry2x32)
 // Restates what jax.random does for  main.py:541-548 / cp_utils.py:31-35 / trigonometric_utils.py:35-38:
 //   keys = split(PRNGKey(seed), S+1)[1:];  angles[j] = uniform(split(keys[j])[1], (P,), 0, 2*pi)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -100,18 +101,22 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
     const std::string cpath = cache_dir() + "/" + hname + ".hsaco";
     std::string code = read_file(cpath);
     const std::string lowered = "cpf_jit_kernel";
+    // ranks of one job may build the same kernel at the same time: private temporaries, atomic rename
+    const std::string tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
     if (code.empty() && use_hipcc) {
         // offline compiler as a subprocess (same flags as the ahead-of-time build)
-        const std::string spath = cache_dir() + "/" + hname + ".hip";
+        const std::string spath = tmp + ".hip";
         std::ofstream(spath) << src;
         const std::string cmd = hipcc + " --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-signed-zeros "
-                                "--genco -I" + inc + " -o " + cpath + ".tmp " + spath + " > " + cpath + ".log 2>&1";
+                                "--genco -I" + inc + " -o " + tmp + " " + spath + " > " + tmp + ".log 2>&1";
         if (system(cmd.c_str()) == 0) {
-            rename((cpath + ".tmp").c_str(), cpath.c_str());
-            code = read_file(cpath);
+            code = read_file(tmp);
+            rename(tmp.c_str(), cpath.c_str());
+            unlink((tmp + ".log").c_str());
         } else if (err) {
-            *err = "hipcc --genco failed, see " + cpath + ".log; ";
+            *err = "hipcc --genco failed, see " + tmp + ".log; ";
         }
+        unlink(spath.c_str());
     }
     if (code.empty()) {
         hiprtcProgram prog;
@@ -137,8 +142,8 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
         code.assign(n, '\0');
         hiprtcGetCode(prog, &code[0]);
         hiprtcDestroyProgram(&prog);
-        std::ofstream(cpath + ".tmp", std::ios::binary) << code;
-        rename((cpath + ".tmp").c_str(), cpath.c_str());
+        { std::ofstream o(tmp, std::ios::binary); o << code; }
+        rename(tmp.c_str(), cpath.c_str());
     }
     Kernel k;
     if (hipModuleLoadData(&k.module, code.data()) != hipSuccess ||

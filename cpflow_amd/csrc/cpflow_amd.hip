@@ -442,6 +442,17 @@ int32_t cpf_unitary_device(const cpf_plan* plan, int64_t S, const float* d_theta
     return launch(plan, a, S, (hipStream_t)stream);
 }
 
+int32_t cpf_reg_device(const cpf_plan* plan, int64_t count, const float* d_theta, float* d_reg, void* stream) {
+    if (!plan) return fail(-1, "plan is NULL");
+    if (count == 0) return 0;
+    if (!d_theta || !d_reg || count < 0) return fail(-1, "NULL buffer");
+    CPF_HIP(hipSetDevice(plan->device));
+    hipLaunchKernelGGL(cpf::k_reg_rows, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       plan->base, d_theta, count, d_reg);
+    CPF_HIP(hipGetLastError());
+    return 0;
+}
+
 int32_t cpf_run_static(const cpf_problem* problem, int32_t device, uint32_t seed, int64_t num_samples_total,
                        int64_t first, int64_t S, int32_t cp_zero, const float* init, const uint8_t* frozen,
                        cpf_result* out) {

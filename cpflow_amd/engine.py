@@ -151,6 +151,7 @@ class TemplateEngine:
         out['passed'] = out['passed'].bool()
         if keep_history:
             out['history_params'], out['history_regloss'] = hp, hl
+            out['history_reg'] = self.reg(hp)
         self._keepalive = (init, fz)
         return out
 
@@ -183,6 +184,16 @@ class TemplateEngine:
                                                   self._ptr(regloss), self._ptr(grad), self._stream()))
         self._keepalive = (theta,)
         return dict(loss=loss, reg=reg, regloss=regloss, grad=grad)
+
+    def reg(self, theta):
+        """r * sum of CP penalties for angle rows [..., P] -> float32 [...] (device tensor)."""
+        theta = self._as_device(theta)
+        shape = theta.shape[:-1]
+        flat = theta.reshape(-1, self.num_angles).contiguous()
+        out = self._empty((flat.shape[0],))
+        _ffi.check(self._lib.cpf_reg_device(self._plan, flat.shape[0], self._ptr(flat), self._ptr(out), self._stream()))
+        self._keepalive = (flat,)
+        return out.reshape(shape)
 
     def unitary(self, theta):
         """complex64 [S, N, N] (or [N, N] for a single angle vector)."""

@@ -292,14 +292,15 @@ class Synthesize:
         fields = {k: out[k] for k in ('params', 'regloss', 'loss', 'reg', 'cz', 'passed')}
         if keep_history:
             fields['history_params'], fields['history_regloss'] = out['history_params'], out['history_regloss']
+            fields['history_reg'] = out['history_reg']
         fields = distributed.gather_samples(fields, S)
         host = {k: v.cpu().numpy() for k, v in fields.items()}
         raw = RawResults()
         for s in range(S):
-            if keep_history:
-                reg_hist = np.zeros_like(host['history_regloss'][s])   # history mode: penalty not split out
-                raw.append({'params': host['history_params'][s], 'loss': host['history_regloss'][s] - reg_hist,
-                            'reg': reg_hist, 'regloss': host['history_regloss'][s]})
+            if keep_history:     # [T, P] / [T] histories, reg recomputed row by row (optimization.py:365-370)
+                raw.append({'params': host['history_params'][s],
+                            'loss': host['history_regloss'][s] - host['history_reg'][s],
+                            'reg': host['history_reg'][s], 'regloss': host['history_regloss'][s]})
             else:
                 raw.append({'params': host['params'][s], 'loss': host['loss'][s], 'reg': host['reg'][s],
                             'regloss': host['regloss'][s]})

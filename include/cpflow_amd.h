@@ -116,6 +116,11 @@ int32_t cpf_loss_grad_device(const cpf_plan* plan, int64_t num_samples, const fl
                              float* d_loss /*[S]*/, float* d_reg /*[S]*/, float* d_regloss /*[S]*/,
                              float* d_grad /*[S][P]*/, void* stream);
 
+/* regularization_func on rows of angles (main.py:563-564): d_reg[i] = r * sum_k R(theta[i][cp_k]).
+ * Used for the keep_history recomputation jit(vmap(vmap(reg))) of optimization.py:365-367. */
+int32_t cpf_reg_device(const cpf_plan* plan, int64_t count, const float* d_theta /*[count][P]*/,
+                       float* d_reg /*[count]*/, void* stream);
+
 /* Ansatz.unitary (main.py:106-146, 186-191): d_unitary [S][N][N][2] complex64 */
 int32_t cpf_unitary_device(const cpf_plan* plan, int64_t num_samples, const float* d_theta /*[S][P]*/,
                            float* d_unitary, void* stream);

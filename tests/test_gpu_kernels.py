@@ -99,6 +99,8 @@ def test_short_adam_trajectory_matches_fp32_oracle(layer, K, rot):
     assert np.abs(out['regloss'].cpu().numpy() - ref['regloss']).max() < 5e-5
     assert np.abs(out['loss'].cpu().numpy() - ref['loss']).max() < 5e-5
     assert np.abs(out['reg'].cpu().numpy() - ref['reg']).max() < 1e-6
+    hreg = orc.loss_grad(hp.reshape(-1, orc.P), np.float64, with_grad=False)['reg'].reshape(S, T)
+    assert np.abs(out['history_reg'].cpu().numpy() - hreg).max() < 1e-6
     assert (out['params'].cpu().numpy()[:, 0] == init).all()
     # the "best" row is one of the visited iterates (pre-update angles), bit for bit
     best = out['params'].cpu().numpy()[:, 1]
