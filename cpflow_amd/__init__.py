@@ -9,5 +9,6 @@ __version__ = '0.1.0'
 
 from .ansatz import Ansatz  # noqa: F401
 from .options import AdaptiveOptions, BasicOptions, RegularizationOptions, StaticOptions  # noqa: F401
-from .synthesis import Decomposition, HSTLoss, Results, Synthesize  # noqa: F401
+from .synthesis import (Decomposition, HSTLoss, RelativePhaseLoss, Results, StatePrepLoss,  # noqa: F401
+                        Synthesize)
 from .topology import chain_layer, connected_layer, fill_layers, num_qubits_from_layer, ring_layer  # noqa: F401

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get('CPF_LIB') or os.path.join(_HERE, 'libcpflow_amd.so') 
 
 ENTANGLER = {'cp': 0, 'cz': 1, 'cx': 2}
 PENALTY = {'linear': 0, 'L1': 1}
+LOSS = {'hst': 0, 'state': 1, 'relative_phase': 2}
 
 
 class Penalty(C.Structure):

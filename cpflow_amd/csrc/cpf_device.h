@@ -63,6 +63,7 @@ struct KArgs {
     const float2* bias;        // [T] {1 - b1^t, 1 - b2^t}, t = 1..T
     Piece pc[10];
     int pen_kind, use_reg;
+    int loss_kind;             // 0 HST / state preparation (|T|^2 form, scale in inv_dim2), 2 relative phase
     float r, lr, b1, b2, eps, omb1, omb2, thr_cp, entry_loss, inv_dim2;
     const float* init;         // [S][P]
     const uint8_t* frozen;     // [S][P] or null
@@ -553,10 +554,16 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         }
         // ---- loss (matrix_utils.py:35-42) and penalty (main.py:563-564)
         float acc[3] = {0.f, 0.f, 0.f};
+        if (a.loss_kind == 2) {
 #pragma unroll
-        for (int e = 0; e < E; e++) {                         // T = sum psi conj(V)
-            acc[0] = fmaf(st.pr[e], vr[e], acc[0]); acc[0] = fmaf(st.pi[e], vi[e], acc[0]);
-            acc[1] = fmaf(st.pi[e], vr[e], acc[1]); acc[1] = fmaf(-st.pr[e], vi[e], acc[1]);
+            for (int e = 0; e < E; e++)                       // sum |V|^2 |psi|^2
+                acc[0] = fmaf(fmaf(vr[e], vr[e], vi[e] * vi[e]), fmaf(st.pr[e], st.pr[e], st.pi[e] * st.pi[e]), acc[0]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) {                     // T = sum psi conj(V)
+                acc[0] = fmaf(st.pr[e], vr[e], acc[0]); acc[0] = fmaf(st.pi[e], vi[e], acc[0]);
+                acc[1] = fmaf(st.pi[e], vr[e], acc[1]); acc[1] = fmaf(-st.pr[e], vi[e], acc[1]);
+            }
         }
         if (a.use_reg) {
             for (int j = tid; j < P; j += L::THREADS) {
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         block_sum<L, 3>(acc, red, wave, lane);
         const float tr = acc[0], ti = acc[1];
         const float ab = sqrtf(fmaf(tr, tr, ti * ti));
-        const float loss = 1.f - ab * ab * a.inv_dim2;
+        const float loss = (a.loss_kind == 2) ? 1.f - tr * a.inv_dim2 : 1.f - ab * ab * a.inv_dim2;
         const float reg = a.use_reg ? a.r * acc[2] : 0.f;
         const float regloss = loss + reg;
 
@@ -593,8 +600,15 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
             if (!a.out_grad) return;
         }
 
-        // ---- backward sweep.  C = (1/2) dL/dU* = -(1/D^2) T V
-        {
+        // ---- backward sweep.  C = (1/2) dL/dU*: -(1/D^2) T V, or -(1/D) |V|^2 psi for the relative-phase loss
+        if (a.loss_kind == 2) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float w = -a.inv_dim2 * fmaf(vr[e], vr[e], vi[e] * vi[e]);
+                st.cr[e] = w * st.pr[e];
+                st.ci[e] = w * st.pi[e];
+            }
+        } else {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
 #pragma unroll
             for (int e = 0; e < E; e++) {

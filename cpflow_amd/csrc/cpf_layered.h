@@ -225,8 +225,12 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         for (int e = 0; e < E; e++) {
             float2 t;
             if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
-            acc[0] = fmaf(st.pr[e], t.x, acc[0]); acc[0] = fmaf(st.pi[e], t.y, acc[0]);
-            acc[1] = fmaf(st.pi[e], t.x, acc[1]); acc[1] = fmaf(-st.pr[e], t.y, acc[1]);
+            if (a.loss_kind == 2) {                   // relative phase: sum |V|^2 |psi|^2
+                acc[0] = fmaf(fmaf(t.x, t.x, t.y * t.y), fmaf(st.pr[e], st.pr[e], st.pi[e] * st.pi[e]), acc[0]);
+            } else {                                  // T = sum psi conj(V)
+                acc[0] = fmaf(st.pr[e], t.x, acc[0]); acc[0] = fmaf(st.pi[e], t.y, acc[0]);
+                acc[1] = fmaf(st.pi[e], t.x, acc[1]); acc[1] = fmaf(-st.pr[e], t.y, acc[1]);
+            }
         }
         if (a.use_reg) {
 #pragma unroll
@@ -236,7 +240,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         const float tr = acc[0], ti = acc[1];
         const float reg = a.use_reg ? a.r * acc[2] : 0.f;
         const float ab = sqrtf(fmaf(tr, tr, ti * ti));
-        const float loss = 1.f - ab * ab * a.inv_dim2;
+        const float loss = (a.loss_kind == 2) ? 1.f - tr * a.inv_dim2 : 1.f - ab * ab * a.inv_dim2;
         const float regloss = loss + reg;
         bool improved = false;
         if (it == 0) { first = regloss; best = regloss; }
@@ -259,8 +263,14 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             for (int e = 0; e < E; e++) {
                 float2 t;
                 if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
-                st.cr[e] = fmaf(fr, t.x, -fi * t.y);
-                st.ci[e] = fmaf(fr, t.y, fi * t.x);
+                if (a.loss_kind == 2) {
+                    const float w = -a.inv_dim2 * fmaf(t.x, t.x, t.y * t.y);
+                    st.cr[e] = w * st.pr[e];
+                    st.ci[e] = w * st.pi[e];
+                } else {
+                    st.cr[e] = fmaf(fr, t.x, -fi * t.y);
+                    st.ci[e] = fmaf(fr, t.y, fi * t.x);
+                }
             }
         }
         float* gslab = smem + Lds::g_surf(K, wave);

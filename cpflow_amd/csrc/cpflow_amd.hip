@@ -98,7 +98,8 @@ int validate(const cpf_problem* pb) {
             return fail(-4, "rotation gate '%c' not in {x,y,z}", pb->rot_axes[i]);
     if (pb->entangler != CPF_ENTANGLER_CP && pb->entangler != CPF_ENTANGLER_CZ)
         return fail(-5, "entangler %d not supported on device (cp, cz)", pb->entangler);
-    if (pb->loss_kind != CPF_LOSS_HST) return fail(-6, "loss_kind %d not supported", pb->loss_kind);
+    if (pb->loss_kind != CPF_LOSS_HST && pb->loss_kind != CPF_LOSS_STATE && pb->loss_kind != CPF_LOSS_RELATIVE_PHASE)
+        return fail(-6, "loss_kind %d not supported", pb->loss_kind);
     if (!pb->target) return fail(-7, "target is NULL");
     for (int b = 0; b < pb->num_blocks; b++) {
         const int p0 = pb->placements[2 * b], p1 = pb->placements[2 * b + 1];
@@ -336,7 +337,11 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     a.lr = (float)pb->lr; a.b1 = b1f; a.b2 = b2f; a.eps = (float)pb->eps;
     a.omb1 = (float)(1.0 - pb->b1); a.omb2 = (float)(1.0 - pb->b2);
     a.thr_cp = (float)pb->threshold_cp; a.entry_loss = (float)pb->entry_loss;
-    a.inv_dim2 = 1.0f / ((float)D * (float)D);
+    // cost_HST: 1 - |T|^2 / D^2.  State preparation: 1 - |<psi|U|0>|^2 is the same |T|^2 form with the state in
+    // column 0 of the target (other columns zero) and unit scale.  Relative phase: 1 - sum |V|^2 |U|^2 / D.
+    a.loss_kind = pb->loss_kind == CPF_LOSS_RELATIVE_PHASE ? 2 : 0;
+    a.inv_dim2 = pb->loss_kind == CPF_LOSS_HST ? 1.0f / ((float)D * (float)D)
+               : (pb->loss_kind == CPF_LOSS_STATE ? 1.0f / (float)(1 << (2 * d)) : 1.0f / (float)D);
     *out_plan = pl;
     return 0;
 }

@@ -37,7 +37,7 @@ class TemplateEngine:
     def __init__(self, layer, num_cp_gates, target_unitary, rotation_gates='xyz', r=0.00055,
                  entangler='cp', use_reg=True, penalty='linear', xmax=math.pi / 2, ymax=2.0,
                  plato_0=0.05, plato_1=0.05, plato_2=0.05, learning_rate=0.1, num_gd_iterations=2000,
-                 threshold_cp=0.2, entry_loss=1e-3, num_qubits=None, device=None, placements=None):
+                 threshold_cp=0.2, entry_loss=1e-3, num_qubits=None, device=None, placements=None, loss='hst'):
         if not torch.cuda.is_available():
             raise _ffi.CpfError('cpflow_amd needs a ROCm GPU: torch.cuda.is_available() is False '
                                 '(there is no CPU fallback).')
@@ -49,8 +49,14 @@ class TemplateEngine:
         self.rotation_gates = str(rotation_gates)
         self.entangler = entangler
         N = 1 << self.num_qubits
-        target = np.ascontiguousarray(np.asarray(target_unitary, dtype=np.complex128))
+        target = np.asarray(target_unitary, dtype=np.complex128)
+        if loss == 'state' and target.ndim == 1:         # target state -> column 0 of an otherwise zero matrix
+            assert target.shape == (N,), 'Number of qubits in target state and layer do not match.'
+            target = np.concatenate([target[:, None], np.zeros((N, N - 1))], axis=1)
+        target = np.ascontiguousarray(target)
         assert target.shape == (N, N), 'Number of qubits in target unitary and layer do not match.'
+        if loss not in _ffi.LOSS:
+            raise ValueError(f"loss '{loss}' not in {sorted(_ffi.LOSS)}")
         self._target = target
         if placements is not None:      # explicit block placements (Ansatz); otherwise the layer is cycled
             self._placements = np.ascontiguousarray(np.asarray(placements, dtype=np.int32).reshape(-1, 2))
@@ -64,7 +70,7 @@ class TemplateEngine:
         pb.n_qubits, pb.num_blocks = self.num_qubits, self.num_cp_gates
         pb.placements = self._placements.ctypes.data
         pb.n_rot, pb.rot_axes = len(self._rot), self._rot
-        pb.entangler, pb.loss_kind = _ffi.ENTANGLER[entangler], 0
+        pb.entangler, pb.loss_kind = _ffi.ENTANGLER[entangler], _ffi.LOSS[loss]
         pb.target = self._target.ctypes.data
         pb.penalty = _ffi.Penalty(_ffi.PENALTY[penalty], xmax, ymax, plato_0, plato_1, plato_2)
         pb.use_reg, pb.r = int(bool(use_reg)), float(r)

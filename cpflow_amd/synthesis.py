@@ -28,6 +28,7 @@ from .topology import fill_layers, num_qubits_from_layer
 class HSTLoss:
     """u -> 1 - |sum(u * conj(target))|^2 / N^2   (cost_HST, cpflow/matrix_utils.py:35-42).
     A picklable object instead of the reference's lambda (cpflow/main.py:533)."""
+    kind = 'hst'
 
     def __init__(self, target_unitary):
         self.target_unitary = np.asarray(target_unitary)
@@ -36,6 +37,34 @@ class HSTLoss:
         u = np.asarray(u)
         n = self.target_unitary.shape[0]
         return 1 - np.abs((u * np.conj(self.target_unitary)).sum()) ** 2 / n ** 2
+
+
+class StatePrepLoss:
+    """u -> 1 - |<psi| u |0>|^2 for a target state psi (tutorial cell 79; the `target_state` the
+    reference's docstring promises, cpflow/main.py:513)."""
+    kind = 'state'
+
+    def __init__(self, target_state):
+        self.target_state = np.asarray(target_state)
+
+    @property
+    def target_unitary(self):          # what the device receives: the state as column 0
+        return self.target_state
+
+    def __call__(self, u):
+        return 1 - np.abs(np.conj(self.target_state) @ np.asarray(u)[:, 0]) ** 2
+
+
+class RelativePhaseLoss:
+    """u -> 1 - sum |conj(V) * u|^2 / N: zero when V^dagger u is diagonal (tutorial cell 87)."""
+    kind = 'relative_phase'
+
+    def __init__(self, target_unitary):
+        self.target_unitary = np.asarray(target_unitary)
+
+    def __call__(self, u):
+        n = self.target_unitary.shape[0]
+        return 1 - (np.abs(np.conj(self.target_unitary) * np.asarray(u)) ** 2).sum() / n
 
 
 def theoretical_lower_bound(n):
@@ -207,15 +236,19 @@ class Synthesize:
     Methods: static(options), adaptive(options).
     """
 
-    def __init__(self, layer, unitary_loss_func=None, target_unitary=None, label=None, cp_regularization_func=None):
+    def __init__(self, layer, unitary_loss_func=None, target_unitary=None, label=None, cp_regularization_func=None,
+                 target_state=None):
         self.layer = layer
         self.num_qubits = num_qubits_from_layer(self.layer)
         self.target_unitary = target_unitary
+        if unitary_loss_func is None and target_state is not None:
+            unitary_loss_func = StatePrepLoss(target_state)
         if unitary_loss_func is not None:
-            if not isinstance(unitary_loss_func, HSTLoss):
+            if not isinstance(unitary_loss_func, (HSTLoss, StatePrepLoss, RelativePhaseLoss)):
                 raise NotImplementedError(
                     'cpflow_amd runs the loss inside a HIP kernel; arbitrary Python loss callables are outside '
-                    'its scope. Pass target_unitary=... (Hilbert-Schmidt loss) or an HSTLoss instance.')
+                    'its scope. Pass target_unitary=... (Hilbert-Schmidt loss), target_state=..., or an HSTLoss / '
+                    'StatePrepLoss / RelativePhaseLoss instance.')
             self.unitary_loss_func = unitary_loss_func
             self.target_unitary = unitary_loss_func.target_unitary
         else:
@@ -254,7 +287,7 @@ class Synthesize:
             self._engines[key] = TemplateEngine(
                 self.layer, kw.pop('num_cp_gates'), self.target_unitary, kw.pop('rotation_gates'),
                 penalty=reg.function, xmax=reg.xmax, ymax=reg.ymax, plato_0=reg.plato_0, plato_1=reg.plato_1,
-                plato_2=reg.plato_2, num_qubits=self.num_qubits, **kw)
+                plato_2=reg.plato_2, num_qubits=self.num_qubits, loss=self.unitary_loss_func.kind, **kw)
         return self._engines[key]
 
     def _raw_engine(self, options):

@@ -42,7 +42,10 @@ extern "C" {
 #define CPF_MIN_QUBITS 2
 
 enum { CPF_ENTANGLER_CP = 0, CPF_ENTANGLER_CZ = 1, CPF_ENTANGLER_CX = 2 };      /* gates.py:40-58 */
-enum { CPF_LOSS_HST = 0 };                                                      /* matrix_utils.py:35-42 cost_HST */
+/* CPF_LOSS_HST: cost_HST (matrix_utils.py:35-42).  CPF_LOSS_STATE: 1 - |<psi|U|0>|^2 with psi = column 0 of
+ * `target` (tutorial cell 79; the other columns are ignored and must be zero).  CPF_LOSS_RELATIVE_PHASE:
+ * 1 - sum |conj(V) o U|^2 / N (tutorial cell 87). */
+enum { CPF_LOSS_HST = 0, CPF_LOSS_STATE = 1, CPF_LOSS_RELATIVE_PHASE = 2 };
 enum { CPF_PENALTY_LINEAR = 0, CPF_PENALTY_L1 = 1 };                            /* penalty.py:44-76 */
 
 /* RegularizationOptions (main.py:328-335) */

@@ -37,7 +37,7 @@ typedef struct {
     int32_t n_rot;
     const char* rot_axes;         /* e.g. "xyz" */
     int32_t entangler;            /* 0 cp, 1 cz, 2 cx */
-    int32_t loss_kind;            /* 0 cost_HST */
+    int32_t loss_kind;            /* 0 cost_HST; 1 state preparation 1-|<psi|U|0>|^2 (psi = target[:,0]); 2 relative phase */
     const double* target;         /* [N][N][2] complex128, row-major */
     cpfo_penalty penalty;
     int32_t use_reg;

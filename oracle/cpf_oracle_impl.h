@@ -260,14 +260,12 @@ static REAL SFX(unitary_loss)(const cpfo_problem* pb, int N, const SFX(cx)* U, c
                  for (int r = 0; r < N; r++) { SFX(cx) p = SFX(cmul)(T, V[r*N]); C[r*N] = (SFX(cx)){-2*p.re, -2*p.im}; } }
         REAL ab = RSQRT(T.re*T.re + T.im*T.im);
         return (REAL)1 - ab * ab;
-    } else {                                  /* relative phase: 1 - sum_c |sum_r conj(V_rc) U_rc|^2 / N ... per column */
+    } else {                                  /* relative phase (tutorial cell 87): 1 - sum_rc |conj(V_rc) U_rc|^2 / N */
         REAL acc = 0;
-        if (C) for (int i = 0; i < NN; i++) C[i] = (SFX(cx)){0, 0};
-        for (int c0 = 0; c0 < N; c0++) {
-            SFX(cx) T = {0, 0};
-            for (int r = 0; r < N; r++) { SFX(cx) p = SFX(cmulc)(U[r*N+c0], V[r*N+c0]); T.re += p.re; T.im += p.im; }
-            acc += T.re*T.re + T.im*T.im;
-            if (C) for (int r = 0; r < N; r++) { SFX(cx) p = SFX(cmul)(T, V[r*N+c0]); C[r*N+c0] = (SFX(cx)){-2*p.re/(REAL)N, -2*p.im/(REAL)N}; }
+        for (int i = 0; i < NN; i++) {
+            REAL v2 = V[i].re * V[i].re + V[i].im * V[i].im;
+            acc += v2 * (U[i].re * U[i].re + U[i].im * U[i].im);
+            if (C) C[i] = (SFX(cx)){-(REAL)2 * v2 * U[i].re / (REAL)N, -(REAL)2 * v2 * U[i].im / (REAL)N};
         }
         return (REAL)1 - acc / (REAL)N;
     }

@@ -198,3 +198,28 @@ def test_abi_errors_on_device():
         eng.optimize(np.zeros((2, eng.num_angles + 1), dtype=np.float32))
     with pytest.raises(NotImplementedError):
         eng.initial_angles(0, 4, cp_dist='normal')
+
+
+@pytest.mark.parametrize('loss,kind', [('state', 1), ('relative_phase', 2)])
+@pytest.mark.parametrize('layer,K', [([[0, 1], [1, 2]], 6), ([[0, 1], [1, 2], [2, 3]], 7), ([[0, 1]], 3)])
+def test_other_loss_kinds_match_oracle(loss, kind, layer, K):
+    """State-preparation loss 1 - |<psi|U|0>|^2 (tutorial cell 79) and relative-phase loss
+    1 - sum |conj(V) o U|^2 / N (cell 87): loss, gradient and short runs against the oracle."""
+    n = max(max(p) for p in layer) + 1
+    N = 2 ** n
+    target = _rand_unitary(n, 9)
+    if loss == 'state':
+        target = np.concatenate([target[:, :1], np.zeros((N, N - 1))], axis=1)
+    T = 15
+    orc = Oracle(layer, K, target, 'xyz', num_gd_iterations=T, loss_kind=kind, r=0.002)
+    eng = _engine(layer, K, target, 'xyz', num_gd_iterations=T, loss=loss, r=0.002)
+    rng = np.random.default_rng(4)
+    theta = rng.uniform(0, 2 * np.pi, size=(6, orc.P)).astype(np.float32)
+    res = eng.loss_and_grad(theta)
+    ref = orc.loss_grad(theta, np.float64)
+    assert np.abs(res['loss'].cpu().numpy() - ref['loss']).max() < 1e-5
+    assert np.abs(res['grad'].cpu().numpy() - ref['grad']).max() < 1e-5
+    out = eng.optimize(theta, keep_history=True)
+    run = orc.run(theta, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'].cpu().numpy() - run['history_loss'])[:, :10].max() < 1e-5
+    assert np.abs(out['regloss'].cpu().numpy() - run['regloss']).max() < 5e-5

@@ -211,3 +211,22 @@ def test_ansatz_unitary_circuit_and_learn():
     hist = anz.learn(target, num_iterations=50, initial_angles=out[0]['params'][0])
     assert hist['params'].shape == (50, anz.num_angles) and hist['loss'].shape == (50,)
     assert (hist['params'][0] == out[0]['params'][0]).all()
+
+
+def test_state_preparation_and_relative_phase_front_end():
+    """Tutorial section 'custom losses': GHZ state preparation on a line (best known: 3 CZ) and the
+    relative-phase Toffoli (3 CZ), through the reference-shaped API with loss objects instead of lambdas."""
+    from cpflow_amd import RelativePhaseLoss, StaticOptions, Synthesize
+    ghz = np.zeros(16)
+    ghz[0] = ghz[15] = 1 / np.sqrt(2)
+    syn = Synthesize([[0, 1], [1, 2], [2, 3]], target_state=ghz, label='GHZ_4q_linear')
+    res = syn.static(StaticOptions(num_cp_gates=4, accepted_num_cz_gates=6, num_samples=64, r=0.002), save_results=False)
+    assert res.decompositions and min(d.cz_count for d in res.decompositions) <= 4
+    for d in res.decompositions:
+        assert d.loss < 1e-5 and abs(abs(np.vdot(ghz, d.unitary[:, 0])) - 1) < 1e-5
+    syn = Synthesize([[0, 1], [1, 2], [0, 2]], unitary_loss_func=RelativePhaseLoss(TOFF3), label='relative_toff3')
+    res = syn.static(StaticOptions(num_cp_gates=6, accepted_num_cz_gates=6, num_samples=64, r=0.002), save_results=False)
+    assert res.decompositions and min(d.cz_count for d in res.decompositions) <= 4
+    d = min(res.decompositions, key=lambda x: x.cz_count)
+    m = TOFF3.conj().T @ d.unitary
+    assert np.abs(m - np.diag(np.diag(m))).max() < 1e-2        # V^dagger U is diagonal
