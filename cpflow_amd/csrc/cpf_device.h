@@ -35,7 +35,7 @@ typedef unsigned long long uint64_t;
 
 namespace cpf {
 
-enum : int { OP_RX = 0, OP_RY = 1, OP_RZ = 2, OP_CP = 3, OP_CZ = 4 };
+enum : int { OP_RX = 0, OP_RY = 1, OP_RZ = 2, OP_CP = 3, OP_CZ = 4, OP_CX = 5 };
 enum : int { MODE_OPTIMIZE = 0, MODE_LOSS_GRAD = 1, MODE_UNITARY = 2 };
 
 struct Piece { float lo, hi, slope, icpt; };
@@ -293,6 +293,33 @@ __device__ __forceinline__ float cp_grad(const State<L>& st) {
     return cp_lane_pred<L, Q0, Q1>(st) ? -2.f * u : 0.f;
 }
 
+// ---- CNOT (gates.py:40-43 cx_mat): control QC ("up"), target QT ("down"); a row permutation, its own inverse
+template <class L, int QC, int QT>
+__device__ __forceinline__ void cx_apply(float (&re)[L::E], float (&im)[L::E], const State<L>& st) {
+    constexpr int BC = L::row_bit(QC), BT = L::row_bit(QT);
+    if constexpr (L::row_on_lane(QT)) {
+#pragma unroll
+        for (int e = 0; e < L::E; e++) {
+            bool ctl;
+            if constexpr (L::row_on_lane(QC)) ctl = st.lb[QC]; else ctl = (e >> BC) & 1;
+            const float qr = xor_lane<BT>(re[e]), qi = xor_lane<BT>(im[e]);
+            re[e] = ctl ? qr : re[e];
+            im[e] = ctl ? qi : im[e];
+        }
+    } else {
+#pragma unroll
+        for (int e0 = 0; e0 < L::E; e0++) {
+            if (e0 & (1 << BT)) continue;
+            const int e1 = e0 | (1 << BT);
+            bool ctl;
+            if constexpr (L::row_on_lane(QC)) ctl = st.lb[QC]; else ctl = (e0 >> BC) & 1;
+            const float r0 = re[e0], i0 = im[e0], r1 = re[e1], i1 = im[e1];
+            re[e0] = ctl ? r1 : r0; im[e0] = ctl ? i1 : i0;
+            re[e1] = ctl ? r0 : r1; im[e1] = ctl ? i0 : i1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ dispatch on (kind, qubit)
 #define CPF_Q_SWITCH(q, BODY)                                            \
     switch (q) {                                                         \
@@ -307,6 +334,15 @@ __device__ __forceinline__ float cp_grad(const State<L>& st) {
 
 #define CPF_PAIR_CASE(A, B)                                              \
     case A * 8 + B: if constexpr (L::NQ > B) { constexpr int Q0 = A, Q1 = B; BODY_PAIR; } break;
+#define CPF_OPAIR_CASE(A, B)                                             \
+    case A * 8 + B: if constexpr (L::NQ > A && L::NQ > B) { constexpr int Q0 = A, Q1 = B; BODY_PAIR; } break;
+#define CPF_ALL_ORDERED_PAIRS                                                                                      \
+    CPF_OPAIR_CASE(0, 1) CPF_OPAIR_CASE(0, 2) CPF_OPAIR_CASE(0, 3) CPF_OPAIR_CASE(0, 4) CPF_OPAIR_CASE(0, 5)       \
+    CPF_OPAIR_CASE(1, 0) CPF_OPAIR_CASE(1, 2) CPF_OPAIR_CASE(1, 3) CPF_OPAIR_CASE(1, 4) CPF_OPAIR_CASE(1, 5)       \
+    CPF_OPAIR_CASE(2, 0) CPF_OPAIR_CASE(2, 1) CPF_OPAIR_CASE(2, 3) CPF_OPAIR_CASE(2, 4) CPF_OPAIR_CASE(2, 5)       \
+    CPF_OPAIR_CASE(3, 0) CPF_OPAIR_CASE(3, 1) CPF_OPAIR_CASE(3, 2) CPF_OPAIR_CASE(3, 4) CPF_OPAIR_CASE(3, 5)       \
+    CPF_OPAIR_CASE(4, 0) CPF_OPAIR_CASE(4, 1) CPF_OPAIR_CASE(4, 2) CPF_OPAIR_CASE(4, 3) CPF_OPAIR_CASE(4, 5)       \
+    CPF_OPAIR_CASE(5, 0) CPF_OPAIR_CASE(5, 1) CPF_OPAIR_CASE(5, 2) CPF_OPAIR_CASE(5, 3) CPF_OPAIR_CASE(5, 4)
 
 // forward application of op to psi
 template <class L>
@@ -315,6 +351,11 @@ __device__ __forceinline__ void op_forward(int kind, int q0, int q1, float c, fl
         case OP_RX: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RX, Q>(st.pr, st.pi, c, s, st))); break;
         case OP_RY: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RY, Q>(st.pr, st.pi, c, s, st))); break;
         case OP_RZ: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RZ, Q>(st.pr, st.pi, c, s, st))); break;
+        case OP_CX: {
+#define BODY_PAIR cx_apply<L, Q0, Q1>(st.pr, st.pi, st)
+            switch (q0 * 8 + q1) { CPF_ALL_ORDERED_PAIRS default: break; }
+#undef BODY_PAIR
+        } break;
         default: {
             if (kind == OP_CZ) { c = -1.f; s = 0.f; }
 #define BODY_PAIR cp_apply<L, Q0, Q1>(st.pr, st.pi, c, s, st)
@@ -343,6 +384,11 @@ __device__ __forceinline__ float op_backward(int kind, int q0, int q1, float c, 
         case OP_RY: CPF_ROT_BWD(OP_RY); break;
         case OP_RZ: CPF_ROT_BWD(OP_RZ); break;
 #undef CPF_ROT_BWD
+        case OP_CX: {
+#define BODY_PAIR (cx_apply<L, Q0, Q1>(st.pr, st.pi, st), cx_apply<L, Q0, Q1>(st.cr, st.ci, st))
+            switch (q0 * 8 + q1) { CPF_ALL_ORDERED_PAIRS default: break; }
+#undef BODY_PAIR
+        } break;
         default: {
             const bool is_cz = (kind == OP_CZ);
             if (is_cz) { c = -1.f; s = 0.f; }

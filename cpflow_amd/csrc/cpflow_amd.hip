@@ -96,8 +96,8 @@ int validate(const cpf_problem* pb) {
     for (int i = 0; i < pb->n_rot; i++)
         if (pb->rot_axes[i] != 'x' && pb->rot_axes[i] != 'y' && pb->rot_axes[i] != 'z')
             return fail(-4, "rotation gate '%c' not in {x,y,z}", pb->rot_axes[i]);
-    if (pb->entangler != CPF_ENTANGLER_CP && pb->entangler != CPF_ENTANGLER_CZ)
-        return fail(-5, "entangler %d not supported on device (cp, cz)", pb->entangler);
+    if (pb->entangler != CPF_ENTANGLER_CP && pb->entangler != CPF_ENTANGLER_CZ && pb->entangler != CPF_ENTANGLER_CX)
+        return fail(-5, "entangler %d not supported (cp, cz, cx)", pb->entangler);
     if (pb->loss_kind != CPF_LOSS_HST && pb->loss_kind != CPF_LOSS_STATE && pb->loss_kind != CPF_LOSS_RELATIVE_PHASE)
         return fail(-6, "loss_kind %d not supported", pb->loss_kind);
     if (!pb->target) return fail(-7, "target is NULL");
@@ -266,8 +266,10 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
         if (pb->entangler == CPF_ENTANGLER_CP) {
             prog.push_back(make_int4(cpf::OP_CP, lo, hi, base + pl->nb - 1));
             pl->h_pkind[base + pl->nb - 1] = 1;
-        } else {
+        } else if (pb->entangler == CPF_ENTANGLER_CZ) {
             prog.push_back(make_int4(cpf::OP_CZ, lo, hi, 0));
+        } else {
+            prog.push_back(make_int4(cpf::OP_CX, up, dn, 0));       // control = up, target = down
         }
         for (int i = 0; i < pb->n_rot; i++) {
             const int kind = pb->rot_axes[i] == 'x' ? cpf::OP_RX : (pb->rot_axes[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
@@ -278,7 +280,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     pl->G = (int)prog.size();
     std::vector<int32_t> pgate((size_t)P, 0);
     for (int g = 0; g < pl->G; g++)
-        if (prog[g].x != cpf::OP_CZ) pgate[prog[g].w] = g;
+        if (prog[g].x != cpf::OP_CZ && prog[g].x != cpf::OP_CX) pgate[prog[g].w] = g;
     // shortest period of the placement sequence = the layer the specialised kernels are built around
     for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
         bool periodic = true;

@@ -223,3 +223,29 @@ def test_other_loss_kinds_match_oracle(loss, kind, layer, K):
     run = orc.run(theta, np.float64, keep_history=True)
     assert np.abs(out['history_regloss'].cpu().numpy() - run['history_loss'])[:, :10].max() < 1e-5
     assert np.abs(out['regloss'].cpu().numpy() - run['regloss']).max() < 5e-5
+
+
+@pytest.mark.parametrize('ent', ['cz', 'cx'])
+@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [2, 1], [0, 2]], 6, 'xyz'), ([[3, 0], [1, 2], [2, 3], [0, 1]], 7, 'xz'),
+                                         ([[0, 5], [4, 2], [1, 3], [5, 1], [2, 0]], 6, 'zy')])
+def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
+    """Ansatz('cz' | 'cx') templates (main.py:72-73, gates.py:40-48): unitary, loss, gradient, short run."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 13)
+    T = 10
+    orc = Oracle(layer, K, target, rot, entangler=ent, num_gd_iterations=T)
+    eng = _engine(layer, K, target, rot, entangler=ent, num_gd_iterations=T, use_reg=False)
+    assert eng.num_angles == orc.P == 3 * n + 2 * len(rot) * K
+    rng = np.random.default_rng(8)
+    theta = rng.uniform(0, 2 * np.pi, size=(4, orc.P)).astype(np.float32)
+    u = eng.unitary(theta).cpu().numpy()
+    for s in range(4):
+        assert np.abs(u[s] - orc.unitary(theta[s], np.float64)).max() < 5e-6
+    res = eng.loss_and_grad(theta)
+    ref = orc.loss_grad(theta, np.float64)
+    assert np.abs(res['loss'].cpu().numpy() - ref['loss']).max() < 1e-5
+    assert np.abs(res['grad'].cpu().numpy() - ref['grad']).max() < 1e-5
+    out = eng.optimize(theta)
+    run = orc.run(theta, np.float64)
+    assert np.abs(out['regloss'].cpu().numpy() - run['regloss']).max() < 2e-5
+    assert (out['cz'].cpu().numpy() == 0).all()
