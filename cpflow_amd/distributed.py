@@ -30,7 +30,7 @@ def shard_capacity(num_samples, world_size):
     return -(-int(num_samples) // int(world_size))
 
 
-def gather_samples(local, num_samples, group=None):
+def gather_samples(local, num_samples, group=None, force_collective=False):
     """All-gather per-sample tensors.
 
     `local` maps name -> tensor whose first dimension is this rank's sample count.  Every
@@ -39,7 +39,7 @@ def gather_samples(local, num_samples, group=None):
     [capacity, width] slab (int32 / bool fields are exactly representable).
     """
     rank, size = world()
-    if size == 1:
+    if size == 1 and not force_collective:
         return local
     names = list(local)
     cap = shard_capacity(num_samples, size)

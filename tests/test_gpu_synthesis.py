@@ -245,3 +245,23 @@ def test_paper_known_answer_K6_cz_ansatz_success_ratio():
                         keep_history=False)
     ratio = np.mean([r['loss'].min() < 1e-4 for r in results])
     assert abs(ratio - 0.31) <= 0.1, ratio        # measured here: 0.31
+
+
+def test_rccl_collective_path_single_rank():
+    """The all-gather runs through RCCL (backend "nccl") on device tensors: one rank here, the same code path as N ranks."""
+    import torch
+    import torch.distributed as dist
+    from cpflow_amd import distributed
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        eng = _engine([[0, 1], [1, 2]], 4, CCZ, 'xyz', num_gd_iterations=20)
+        out = eng.optimize(eng.initial_angles(0, 9))
+        fields = {k: out[k] for k in ('params', 'regloss', 'loss', 'reg', 'cz', 'passed')}
+        got = distributed.gather_samples(fields, 9, force_collective=True)
+        for k in fields:
+            assert got[k].dtype == fields[k].dtype and torch.equal(got[k], fields[k])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
