@@ -265,3 +265,30 @@ def test_rccl_collective_path_single_rank():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['raw_toff3_chain_t49', 'raw_toff3_chain_t19', 'raw_toff4_star_t14', 'raw_toff4_star_t49',
+                                  'raw_toff3_conn_t99', 'raw_4gt10_xz_t30', 'raw_4gt13_xyz_t99'])
+def test_T0_T1_all_golden_fixtures(name):
+    """Every stored trial (3q / 4q / 5q, 'xyz' / 'xz'): the device draws the reference's initial angles bit for bit
+    and reproduces its loss / reg / regloss at the stored {initial, best} angles (float32, 1.5e-5)."""
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    eng = _engine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
+    S, idx = int(g['num_samples']), g['sample_index']
+    lo, hi = int(idx.min()), int(idx.max()) + 1
+    rows = eng.initial_angles(int(g['seed']), S, first=lo, count=hi - lo).cpu().numpy()
+    assert (rows[idx - lo].view(np.uint32) == g['params'][:, 0].view(np.uint32)).all()
+    # float32 noise grows with depth: 1.5e-5 up to 40 blocks; the 5-qubit K = 57 / 86 trials get 3e-5
+    # (SURVEY App. D: the survey's own restatement saw 1.2e-5 on the K = 86 file)
+    tol = 1.5e-5 if int(g['num_cp_gates']) <= 40 else 3e-5
+    for k in (0, 1):
+        at = _np(eng.loss_and_grad(g['params'][:, k, :], with_grad=False))
+        assert np.abs(at['loss'] - g['loss'][:, k]).max() < tol
+        if bool(g['pin_reg']):
+            assert np.abs(at['reg'] - g['reg'][:, k]).max() < 1e-7
+            assert np.abs(at['regloss'] - g['regloss'][:, k]).max() < tol
+    # the stored CZ counts follow from the stored best angles (device evaluation with zero iterations)
+    ev = _engine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']),
+                 num_gd_iterations=0)
+    best = g['params'][np.arange(len(idx)), g['regloss'].argmin(1)]
+    assert (_np(ev.optimize(best))['cz'] == g['cz']).all()
