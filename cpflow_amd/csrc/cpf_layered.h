@@ -181,43 +181,41 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
 #pragma unroll
         for (int e = 0; e < E; e++) { st.pr[e] = (L::row_index(lane, e) == col) ? 1.f : 0.f; st.pi[e] = 0.f; }
         {
-            float sr[Lds::SURF_F];
+            // two record buffers used alternately with a compile-time parity (no register copies): a body
+            // covers UNR blocks = one layer, or two layers when the layer length is odd.  The first block
+            // record is issued together with the surface record so both arrive under one LDS latency.
+            float sr[Lds::SURF_F], ra[16], rb[16];
 #pragma unroll
             for (int i = 0; i < Lds::SURF_F / 4; i++) {
                 const float4 v = reinterpret_cast<const float4*>(smem + Lds::SURF_CS)[i];
                 sr[4 * i] = v.x; sr[4 * i + 1] = v.y; sr[4 * i + 2] = v.z; sr[4 * i + 3] = v.w;
             }
+            if constexpr (E < 16) { if (K > 0) load_rec(smem + Lds::BLK_CS, ra); }
             static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
                 constexpr int Q = decltype(qq)::value;
                 rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q], sr[6 * Q + 1], st);
                 rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
                 rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
             }, typename make_iseq<NQ>::type{});
-        }
-        if (K > 0) {
-            // two record buffers used alternately with a compile-time parity (no register copies):
-            // the body covers UNR blocks = one layer, or two layers when the layer length is odd
-            float ra[16], rb[16];
             int b = 0;
-            if constexpr (E < 16) load_rec(smem + Lds::BLK_CS, ra);
-            while (b < K) {
-                static_for([&](auto jj) __attribute__((always_inline)) {
-                    constexpr int J = decltype(jj)::value, I = J % LL;
-                    if (b < K) {
-                        if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
-                            load_rec(smem + Lds::BLK_CS + 16 * b, ra);
-                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
-                        } else if constexpr ((J & 1) == 0) {
-                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rb);      // prefetch next record
-                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
-                        } else {
-                            load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), ra);
-                            lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb);
-                        }
-                        b++;
-                    }
-                }, typename make_iseq<UNR>::type{});
-            }
+            auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
+                constexpr int J = decltype(jj)::value, I = J % LL;
+                if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
+                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                    lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
+                } else if constexpr ((J & 1) == 0) {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), rb);      // prefetch next record
+                    lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
+                } else {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), ra);
+                    lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb);
+                }
+                b++;
+            };
+            for (int full = K / UNR; full > 0; full--)             // whole bodies: straight-line, no guards
+                static_for(fwd_step, typename make_iseq<UNR>::type{});
+            static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); },   // tail: K % UNR blocks
+                       typename make_iseq<UNR>::type{});
         }
         // ================= loss, penalty, best tracking
         float acc[3] = {0.f, 0.f, 0.f};
@@ -277,39 +275,38 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         if (K > 0) {
             float ra[16], rb[16], d[8];
             int b = K - 1;
-            // the truncated last layer first (blocks on pairs K % LL - 1 .. 0, no prefetch), then full layers
-            const int rem = K % LL;
-            static_for([&](auto ii) __attribute__((always_inline)) {
-                constexpr int I = LL - 1 - decltype(ii)::value;
-                if (I < rem) {
+            // blocks K-1 .. 0.  First the K % UNR blocks beyond the last whole body (no prefetch), then whole
+            // bodies of UNR blocks in reverse with compile-time pair index and buffer parity.
+            const int tail = K % UNR;
+            static_for([&](auto jj) __attribute__((always_inline)) {
+                constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL;      // J = position inside the body
+                if (J < tail) {
                     load_rec(smem + Lds::BLK_CS + 16 * b, ra);
                     lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
                     reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
                     gate_fence<L>();
                     b--;
                 }
-            }, typename make_iseq<LL>::type{});
+            }, typename make_iseq<UNR>::type{});
             if constexpr (E < 16) { if (b >= 0) load_rec(smem + Lds::BLK_CS + 16 * b, ra); }
-            while (b >= 0) {
-                static_for([&](auto jj) __attribute__((always_inline)) {
-                    constexpr int J = decltype(jj)::value, I = LL - 1 - (J % LL);
-                    if (b >= 0) {
-                        if constexpr (E >= 16) {
-                            load_rec(smem + Lds::BLK_CS + 16 * b, ra);
-                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
-                        } else if constexpr ((J & 1) == 0) {
-                            load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
-                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
-                        } else {
-                            load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), ra);
-                            lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb, d);
-                        }
-                        reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
-                        gate_fence<L>();
-                        b--;
-                    }
-                }, typename make_iseq<UNR>::type{});
-            }
+            auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
+                constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL;
+                if constexpr (E >= 16) {
+                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
+                } else if constexpr ((JJ & 1) == 0) {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
+                } else {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), ra);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb, d);
+                }
+                reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
+                gate_fence<L>();
+                b--;
+            };
+            for (int full = K / UNR; full > 0; full--)
+                static_for(bwd_step, typename make_iseq<UNR>::type{});
         }
         {
             float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
