@@ -64,10 +64,10 @@ inline std::map<std::string, Kernel>& table() { static std::map<std::string, Ker
 inline std::mutex& table_mutex() { static std::mutex m; return m; }
 
 // Returns nullptr (and fills err) when the kernel cannot be produced.
-inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int ppt, const std::vector<int>& ud,
+inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int ppt, int mstore, const std::vector<int>& ud,
                                  std::string* err) {
     std::ostringstream name;
-    name << "cpf::k_cp_layered<" << nq << ", " << lw << ", " << rot_code << ", " << ppt;
+    name << "cpf::k_cp_layered<" << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
     for (int v : ud) name << ", " << v;
     name << ">";
     const std::string expr = name.str();
@@ -81,7 +81,7 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
     if (hdrs.size() < 1000) { if (err) *err = "kernel headers not found under " + inc; return nullptr; }
     // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
     std::ostringstream targs;
-    targs << nq << ", " << lw << ", " << rot_code << ", " << ppt;
+    targs << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
     for (int v : ud) targs << ", " << v;
     const std::string src = "#include \"cpf_layered.h\"\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(64 << lw) + ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    cpf::layered_body<" +

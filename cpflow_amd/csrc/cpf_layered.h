@@ -34,8 +34,71 @@ struct LayeredLds {                                       // float offsets; [0, 
     __host__ __device__ static constexpr int g_surf(int K, int w) { return g_base(K) + w * g_wave(K); }
     __host__ __device__ static constexpr int g_blk(int K, int w, int b) { return g_surf(K, w) + 32 * NBATCH + 32 * b; }
     __host__ __device__ static constexpr int red(int K, int wps) { return g_base(K) + wps * g_wave(K); }
-    __host__ __device__ static constexpr int total(int K, int wps) { return red(K, wps) + 8 * wps + 4; }
+    // stored merged-diagonal phases (3-qubit kernel, MSTORE = 1): (K + 1) units x 64 lanes x (re, im)
+    __host__ __device__ static constexpr int phase(int K, int wps) { return red(K, wps) + 8 * wps + 4; }
+    __host__ __device__ static constexpr int total(int K, int wps, bool merge) {
+        return phase(K, wps) + (merge ? 128 * (K + 1) : 0);
+    }
 };
+
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s);
+template <class L>
+__device__ __forceinline__ void gate_fence();
+
+// Merging runs of diagonal gates (one element per lane, rotation string ending in 'z').  In program order the
+// circuit reads ... Rz(up) Rz(dn) | CP(next block) ...: three diagonal gates in a row.  Forward, their product is
+// one per-lane phase rho (12 ops to build, 4 to apply: what the three gates cost anyway), which is also stored
+// in LDS (8 bytes per lane).  Backward, conj(C) psi is invariant under a common phase, so the three angle
+// gradients share one product w = Im(conj(C) psi), and un-applying the run is one complex multiply by
+// conj(rho) for psi and one for C: 15 ops instead of 37 per block.
+__host__ __device__ constexpr bool layered_merge(int nq, int lw, int rot) {
+    return nq == 3 && lw == 0 && rot_nr(rot) >= 1 && rot_kind(rot, rot_nr(rot) - 1) == OP_RZ;
+}
+template <class L, int PUP, int PDN, int UP, int DN>
+__device__ __forceinline__ float2 diag_phase(const State<L>& st, float cu, float su, float cd, float sd, float cc, float sc) {
+    constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
+    const float ssu = st.sg[PUP] * su, ssd = st.sg[PDN] * sd;          // Rz(a) multiplies by cos(a/2) + i sigma sin(a/2)
+    const float t1 = fmaf(-ssu, ssd, cu * cd), t2 = fmaf(cu, ssd, ssu * cd);
+    const bool p = cp_lane_pred<L, Q0, Q1>(st);                        // CP multiplies the |11> rows by e^{ia}
+    const float ce = p ? cc : 1.f, se = p ? sc : 0.f;
+    return make_float2(fmaf(-t2, se, t1 * ce), fmaf(t2, ce, t1 * se));
+}
+template <class L>
+__device__ __forceinline__ void phase_apply(float& re, float& im, float2 rho, bool conj) {
+    const float qi = conj ? -rho.y : rho.y;
+    const float nr = fmaf(-qi, im, rho.x * re), ni = fmaf(qi, re, rho.x * im);
+    re = nr; im = ni;
+}
+// the rotations of a block except the final letter's pair (used with merged diagonal runs)
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_fwd_inner(State<L>& st, const float (&r)[16]) {
+    constexpr int NR = rot_nr(ROT);
+#pragma unroll
+    for (int i = 0; i < NR - 1; i++) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+        } else {
+            rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+        }
+    }
+}
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_bwd_inner(State<L>& st, const float (&r)[16], float (&d)[8]) {
+    constexpr int NR = rot_nr(ROT);
+#pragma unroll
+    for (int i = NR - 2; i >= 0; i--) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP>(st, r[4 * i], r[4 * i + 1]);
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP>(st, r[4 * i], r[4 * i + 1]);
+        } else {
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
+        }
+    }
+}
 
 // With 16+ elements per thread a layer body is a basic block of ~10^4 instructions; left alone the
 // scheduler interleaves gates and drives the kernel into scratch (measured: 248 VGPRs + 464 B/lane,
@@ -100,7 +163,8 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
 }
 
 // UD... = up0, dn0, up1, dn1, ...: the layer (topology.py:15-20: block b sits on pair b mod len)
-template <int NQ, int LW, int ROT, int PPT, int... UD>
+// MSTORE: see STORE below (only meaningful when layered_merge(NQ, LW, ROT))
+template <int NQ, int LW, int ROT, int PPT, int MSTORE, int... UD>
 __device__ __forceinline__ void layered_body(const KArgs& a) {
     using L = Lay<NQ, LW>;
     using Lds = LayeredLds<NQ>;
@@ -109,6 +173,10 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     constexpr int LL = sizeof...(UD) / 2;
     constexpr int UNR = (LL % 2 == 0) ? LL : 2 * LL;      // blocks per unrolled loop body (even, for buffer parity)
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
+    constexpr bool MERGE = layered_merge(NQ, LW, ROT);
+    // MSTORE = 1: the forward pass keeps each run's phase in LDS (8 B per lane per block) for the backward pass;
+    // MSTORE = 0: the backward pass rebuilds it (12 more ops per block, no LDS: better once LDS limits occupancy)
+    constexpr bool STORE = MERGE && (MSTORE != 0);
     static_assert(LL >= 1 && NR >= 1 && NR <= 3, "layered kernel: 1..3 rotation letters, non-empty layer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -119,6 +187,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
     float* red = smem + Lds::red(K, WPS);
+    float2* ph = reinterpret_cast<float2*>(smem + Lds::phase(K, WPS)) + lane;      // MERGE: unit u at ph[64 * u]
 
     State<L> st;
 #pragma unroll
@@ -198,9 +267,22 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                 rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
             }, typename make_iseq<NQ>::type{});
             int b = 0;
+            float pz[4] = {1.f, 0.f, 1.f, 0.f};          // MERGE: (cos, sin) of the previous block's final Rz pair
             auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
                 constexpr int J = decltype(jj)::value, I = J % LL;
-                if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
+                if constexpr (MERGE) {
+                    constexpr int IP = ((J + UNR - 1) % UNR) % LL;                 // pair of the previous block
+                    float (&cur)[16] = (J & 1) ? rb : ra;
+                    float (&nxt)[16] = (J & 1) ? ra : rb;
+                    const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                        st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+                    if constexpr (STORE) ph[64 * b] = rho;
+                    phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+                    load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), nxt);
+                    lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
+                } else if constexpr (E >= 16) {            // long blocks: no prefetch, keep registers
                     load_rec(smem + Lds::BLK_CS + 16 * b, ra);
                     lay_block_fwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra);
                 } else if constexpr ((J & 1) == 0) {
@@ -216,6 +298,20 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                 static_for(fwd_step, typename make_iseq<UNR>::type{});
             static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); },   // tail: K % UNR blocks
                        typename make_iseq<UNR>::type{});
+            if constexpr (MERGE) {                   // the last block's Rz pair, not followed by a CP
+                if (K > 0) {
+                    const int jt = (K - 1) % UNR;
+                    static_for([&](auto jj) __attribute__((always_inline)) {
+                        constexpr int J = decltype(jj)::value, I = J % LL;
+                        if (J == jt) {
+                            const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                                st, pz[0], pz[1], pz[2], pz[3], 1.f, 0.f);
+                            if constexpr (STORE) ph[64 * K] = rho;
+                            phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+                        }
+                    }, typename make_iseq<UNR>::type{});
+                }
+            }
         }
         // ================= loss, penalty, best tracking
         float acc[3] = {0.f, 0.f, 0.f};
@@ -275,35 +371,87 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         if (K > 0) {
             float ra[16], rb[16], d[8];
             int b = K - 1;
-            // blocks K-1 .. 0.  First the K % UNR blocks beyond the last whole body (no prefetch), then whole
-            // bodies of UNR blocks in reverse with compile-time pair index and buffer parity.
-            const int tail = K % UNR;
-            static_for([&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL;      // J = position inside the body
-                if (J < tail) {
-                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
-                    reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
-                    gate_fence<L>();
-                    b--;
-                }
-            }, typename make_iseq<UNR>::type{});
-            if constexpr (E < 16) { if (b >= 0) load_rec(smem + Lds::BLK_CS + 16 * b, ra); }
-            auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
-                constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL;
-                if constexpr (E >= 16) {
-                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
-                } else if constexpr ((JJ & 1) == 0) {
-                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, ra, d);
+            float dzu = 0.f, dzd = 0.f;              // MERGE: gradients of block b's final Rz pair, found one unit earlier
+            if constexpr (E < 16) load_rec(smem + Lds::BLK_CS + 16 * b, ra);      // record of block K-1
+            if constexpr (MERGE) {
+                const int jt = (K - 1) % UNR;
+                float2 rho = make_float2(1.f, 0.f);
+                if constexpr (STORE) rho = ph[64 * K];
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jj)::value, I = J % LL;
+                    if (J == jt) {
+                        if constexpr (!STORE)
+                            rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                                st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
+                        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+                        dzu = -st.sg[PL::v[2 * I]] * w;
+                        dzd = -st.sg[PL::v[2 * I + 1]] * w;
+                    }
+                }, typename make_iseq<UNR>::type{});
+                phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+                phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+            }
+            // one block of the backward sweep; CUR = its record
+            auto bwd_block = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
+                constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
+                if constexpr (MERGE) {
+                    float2 rho;
+                    if constexpr (STORE) rho = ph[64 * b];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) d[k] = 0.f;
+                    lay_block_bwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, d);
+                    if constexpr (!STORE) {            // rebuild the run's phase: Rz pair of block b-1 (record prv) and CP(b)
+                        const bool has_prev = b > 0;
+                        rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                            st, has_prev ? prv[4 * (NR - 1)] : 1.f, has_prev ? prv[4 * (NR - 1) + 1] : 0.f,
+                            has_prev ? prv[4 * (NR - 1) + 2] : 1.f, has_prev ? prv[4 * (NR - 1) + 3] : 0.f,
+                            cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+                    }
+                    d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
+                    const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);     // shared by CP(b), Rz(up), Rz(dn) of block b-1
+                    constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
+                    constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
+                    d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+                    dzu = -st.sg[PL::v[2 * IP]] * w;
+                    dzd = -st.sg[PL::v[2 * IP + 1]] * w;
+                    phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+                    phase_apply<L>(st.cr[0], st.ci[0], rho, true);
                 } else {
-                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), ra);
-                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, rb, d);
+                    lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, d);
                 }
                 reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
                 gate_fence<L>();
                 b--;
+            };
+            // blocks K-1 .. 0.  First the K % UNR blocks beyond the last whole body (no prefetch), then whole
+            // bodies of UNR blocks in reverse with compile-time pair index and buffer parity.
+            const int tail = K % UNR;
+            static_for([&](auto jj) __attribute__((always_inline)) {
+                constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+                if (J < tail) {
+                    if constexpr (MERGE) {            // (tail blocks: plain loads, record b in ra, record b-1 in rb)
+                        load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                        load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
+                        bwd_block(ic<I>{}, ic<IP>{}, ra, rb);
+                    } else {
+                        load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                        bwd_block(ic<I>{}, ic<IP>{}, ra, ra);
+                    }
+                }
+            }, typename make_iseq<UNR>::type{});
+            if constexpr (E < 16) { if (b >= 0 && tail > 0) load_rec(smem + Lds::BLK_CS + 16 * b, ra); }
+            auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
+                constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+                if constexpr (E >= 16) {
+                    load_rec(smem + Lds::BLK_CS + 16 * b, ra);
+                    bwd_block(ic<I>{}, ic<IP>{}, ra, ra);
+                } else if constexpr ((JJ & 1) == 0) {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), rb);
+                    bwd_block(ic<I>{}, ic<IP>{}, ra, rb);
+                } else {
+                    load_rec(smem + Lds::BLK_CS + 16 * (b > 0 ? b - 1 : 0), ra);
+                    bwd_block(ic<I>{}, ic<IP>{}, rb, ra);
+                }
             };
             for (int full = K / UNR; full > 0; full--)
                 static_for(bwd_step, typename make_iseq<UNR>::type{});
@@ -380,9 +528,9 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     }
 }
 
-template <int NQ, int LW, int ROT, int PPT, int... UD>
+template <int NQ, int LW, int ROT, int PPT, int MSTORE, int... UD>
 __global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
-    layered_body<NQ, LW, ROT, PPT, UD...>(a);
+    layered_body<NQ, LW, ROT, PPT, MSTORE, UD...>(a);
 }
 
 }  // namespace cpf

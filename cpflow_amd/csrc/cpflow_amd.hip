@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -126,18 +127,33 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
 
 // Ahead-of-time instances of the layered kernel: 3 qubits, the reference's two layer constructors
 // (chain_layer(3), connected_layer(3); topology.py:7-12), 'xyz' / 'xz', optimiser state for <= 128 / 256 angles.
+// Stored phases cost 512 (K + 1) bytes of LDS per sample: use them while that does not cut the number of
+// resident workgroups the launch needs (S / CUs, at most ~5 per SIMD by registers).
+bool phases_fit(int num_cu, int64_t S, size_t lds_bytes_with_phases) {
+    { const char* e = getenv("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    // same-box A/B (ms, store vs rebuild): config 2 S=1024 10.06/10.53, S=4096 24.45/26.15, S=16384 96.1/93.5;
+    // config 3 S=1024 12.89/13.75, S=4096 38.5/35.4 -> store only while LDS still admits the workgroups the launch
+    // wants per CU (registers cap that at ~20)
+    const int64_t want = std::min<int64_t>((S + num_cu - 1) / num_cu, 20);
+    return (int64_t)(160 * 1024 / lds_bytes_with_phases) >= want;
+}
 template <int ROT, int PPT, int... UD>
-int launch_layered3(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
-    const size_t lds = (size_t)cpf::LayeredLds<3>::total(K, 1) * sizeof(float);
-    hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, UD...>), dim3((unsigned)S), dim3(64), lds, stream, a);
+int launch_layered3(const cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    const bool merge = cpf::layered_merge(3, 0, ROT);
+    const size_t lds1 = (size_t)cpf::LayeredLds<3>::total(K, 1, merge) * sizeof(float);
+    const size_t lds0 = (size_t)cpf::LayeredLds<3>::total(K, 1, false) * sizeof(float);
+    if (merge && lds1 <= 64 * 1024 && phases_fit(plan->num_cu, S, lds1))
+        hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, 1, UD...>), dim3((unsigned)S), dim3(64), lds1, stream, a);
+    else
+        hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, 0, UD...>), dim3((unsigned)S), dim3(64), lds0, stream, a);
     CPF_HIP(hipGetLastError());
     return 0;
 }
 template <int ROT, int PPT>
 bool launch_layered3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
     const std::vector<int>& ud = plan->layer_ud;
-    if (ud == std::vector<int>{0, 1, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 1, 2>(a, plan->K, S, stream); return true; }
-    if (ud == std::vector<int>{0, 1, 0, 2, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 0, 2, 1, 2>(a, plan->K, S, stream); return true; }
+    if (ud == std::vector<int>{0, 1, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 1, 2>(plan, a, plan->K, S, stream); return true; }
+    if (ud == std::vector<int>{0, 1, 0, 2, 1, 2}) { *rc = launch_layered3<ROT, PPT, 0, 1, 0, 2, 1, 2>(plan, a, plan->K, S, stream); return true; }
     return false;
 }
 bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
@@ -167,17 +183,22 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     for (int i = 0; i < plan->n_rot; i++) kinds[i] = plan->rot[i] == 'x' ? cpf::OP_RX : (plan->rot[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
     const int rot_code = cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]);
     size_t lds = 0;
+    int mstore = 0;
+    if (plan->NQ == 3 && cpf::layered_merge(3, lw, rot_code)) {
+        const size_t with = (size_t)cpf::LayeredLds<3>::total(plan->K, 1, true) * sizeof(float);
+        mstore = (with <= 64 * 1024 && phases_fit(plan->num_cu, S, with)) ? 1 : 0;
+    }
     switch (plan->NQ) {
-        case 3: lds = cpf::LayeredLds<3>::total(plan->K, 1 << lw); break;
-        case 4: lds = cpf::LayeredLds<4>::total(plan->K, 1 << lw); break;
-        case 5: lds = cpf::LayeredLds<5>::total(plan->K, 1 << lw); break;
-        case 6: lds = cpf::LayeredLds<6>::total(plan->K, 1 << lw); break;
+        case 3: lds = cpf::LayeredLds<3>::total(plan->K, 1 << lw, mstore != 0); break;
+        case 4: lds = cpf::LayeredLds<4>::total(plan->K, 1 << lw, false); break;
+        case 5: lds = cpf::LayeredLds<5>::total(plan->K, 1 << lw, false); break;
+        case 6: lds = cpf::LayeredLds<6>::total(plan->K, 1 << lw, false); break;
         default: return false;
     }
     lds *= sizeof(float);
     if (lds > 64 * 1024) { plan->jit_note = "LDS footprint above 64 KiB"; return false; }
     std::string err;
-    hipFunction_t fn = cpf_jit::get_layered(plan->device, plan->NQ, lw, rot_code, ppt, plan->layer_ud, &err);
+    hipFunction_t fn = cpf_jit::get_layered(plan->device, plan->NQ, lw, rot_code, ppt, mstore, plan->layer_ud, &err);
     if (!fn) { plan->jit_note = err; return false; }
     cpf::KArgs args = a;
     void* params[] = {&args};

@@ -249,3 +249,27 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
     run = orc.run(theta, np.float64)
     assert np.abs(out['regloss'].cpu().numpy() - run['regloss']).max() < 2e-5
     assert (out['cz'].cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize('mstore', ['0', '1'])
+@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 12, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 16, 'xyz'),
+                                         ([[0, 1], [1, 2]], 7, 'xz'), ([[2, 0], [1, 2], [0, 1]], 5, 'xyz'),
+                                         ([[0, 1], [0, 2], [1, 2]], 1, 'xz'), ([[1, 0], [2, 0]], 4, 'yz')])
+def test_merged_diagonal_runs_both_variants(layer, K, rot, mstore, monkeypatch):
+    """3-qubit kernels merge each run Rz(up) Rz(dn) CP(next) into one phase; the phase is either kept in LDS
+    for the backward pass (CPF_MSTORE=1) or rebuilt there (0).  Both against the float64 oracle, including
+    truncated layers, twisted pairs, a single block and a 2-letter rotation string."""
+    n = 3
+    target = _rand_unitary(n, 21)
+    T, S = 14, 5
+    monkeypatch.setenv('CPF_MSTORE', mstore)
+    orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
+    eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
+    init = orc.initial_angles(9, S)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant().startswith('layered/'), eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'] - ref['history_loss'])[:, :10].max() < 1e-5
+    assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 3e-5
+    assert np.abs(out['history_params'] - ref['history_params'])[:, :10].max() < 1e-4
+    assert (out['cz'] == ref['cz']).all()
