@@ -47,14 +47,21 @@ inline uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
-inline std::string cache_dir() {
-    const char* e = getenv("CPF_JIT_CACHE");
-    std::string d = e ? std::string(e) : std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/cpflow_amd";
+inline bool make_dirs(const std::string& d) {
     std::string acc;
     for (size_t i = 0; i <= d.size(); i++)
         if (i == d.size() || d[i] == '/') { if (!acc.empty()) mkdir(acc.c_str(), 0755); if (i < d.size()) acc += '/'; }
         else acc += d[i];
-    return d;
+    struct stat st;
+    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && access(d.c_str(), W_OK) == 0;
+}
+inline std::string cache_dir() {
+    const char* e = getenv("CPF_JIT_CACHE");
+    const std::string first = e ? std::string(e) : std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/cpflow_amd";
+    if (make_dirs(first)) return first;
+    const std::string fallback = "/tmp/cpflow_amd_cache_" + std::to_string((long)getuid());      // read-only home
+    make_dirs(fallback);
+    return fallback;
 }
 
 struct Kernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; };

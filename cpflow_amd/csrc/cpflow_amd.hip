@@ -171,6 +171,35 @@ bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipS
     return false;
 }
 
+// Ahead-of-time instances for the two larger BASELINE configurations, so that they do not depend on a compiler
+// being present at run time: 4 qubits chain_layer(4) (config 4: K = 24, 180 angles, 1 wave) and 6 qubits on a
+// ring (config 5: K = 60, 438 angles, 4 waves).
+template <int NQ, int LW, int ROT, int PPT, int... UD>
+int launch_layered_aot(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    const size_t lds = (size_t)cpf::LayeredLds<NQ>::total(K, 1 << LW, false) * sizeof(float);
+    if (lds > 64 * 1024) return fail(-20, "LDS footprint above 64 KiB");
+    hipLaunchKernelGGL((cpf::k_cp_layered<NQ, LW, ROT, PPT, 0, UD...>), dim3((unsigned)S), dim3(64 << LW), lds, stream, a);
+    CPF_HIP(hipGetLastError());
+    return 0;
+}
+bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
+    { const char* e = getenv("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
+    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP ||
+        plan->rot != "xyz")
+        return false;
+    constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
+    const int ppt = (a.P + (64 << lw) - 1) / (64 << lw);
+    if (plan->NQ == 4 && lw == 0 && ppt == 3 && plan->layer_ud == std::vector<int>{0, 1, 1, 2, 2, 3}) {
+        *rc = launch_layered_aot<4, 0, XYZ, 3, 0, 1, 1, 2, 2, 3>(a, plan->K, S, stream);
+        return true;
+    }
+    if (plan->NQ == 6 && lw == 2 && ppt == 2 && plan->layer_ud == std::vector<int>{0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}) {
+        *rc = launch_layered_aot<6, 2, XYZ, 2, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0>(a, plan->K, S, stream);
+        return true;
+    }
+    return false;
+}
+
 // Runtime-specialised layered kernel (cpf_layered.h through hiprtc).  lw = log2(waves per sample).
 bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
     plan->jit_note.clear();
@@ -230,6 +259,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     }
     { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
+    if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1"); return rc; }
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
     switch (plan->NQ) {
