@@ -443,6 +443,13 @@ __device__ __forceinline__ float penalty_lds(const float* tab, int pen_kind, flo
     slope = si.x;
     return __fadd_rn(__fmul_rn(si.x, x), si.y);
 }
+// the same in two halves, so that the table lookups are in flight while other work (sincos) executes
+__device__ __forceinline__ float2 penalty_lookup(const float* tab, float x) {
+    const float4 l0 = *reinterpret_cast<const float4*>(tab + PEN_LO);
+    const float4 l1 = *reinterpret_cast<const float4*>(tab + PEN_LO + 4);
+    const int idx = (x > l0.x) + (x > l0.y) + (x > l0.z) + (x > l0.w) + (x > l1.x) + (x > l1.y) + (x > l1.z) + (x > l1.w);
+    return *reinterpret_cast<const float2*>(tab + PEN_SI + 2 * idx);
+}
 // cp_utils.py:45-50 cz_value
 __device__ __forceinline__ float cz_value(float ang, float t) {
     const float pi = 3.1415927f, twopi = 6.2831855f;

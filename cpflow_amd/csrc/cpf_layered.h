@@ -232,10 +232,17 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     }
     for (int b = tid; b < K; b += THREADS) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
     auto publish = [&](int s) __attribute__((always_inline)) {
+        // linear penalty: start the two LDS table lookups first, so they are in flight during sincos
+        const bool pen = a.use_reg && (K > THREADS * s) && is_cp[s];
+        const bool lin = pen && a.pen_kind == 0;
+        float x = 0.f;
+        float2 si = make_float2(0.f, 0.f);
+        if (lin) { x = floor_mod_2pi(th[s]); si = penalty_lookup(smem, x); }
         float sn, cn;
         sincosf(is_cp[s] ? th[s] : 0.5f * th[s], &sn, &cn);       // 3.4 % of config 2's kernel time
         if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
-        if (a.use_reg && (K > THREADS * s) && is_cp[s]) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
+        if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
+        else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
     };
     lds_sync<WPS>();
 #pragma unroll

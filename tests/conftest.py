@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _native_libraries():
+    """Build the HIP library / the C oracle when a checkout has not been built yet (hipcc and gcc are in the
+    image; on the GPU box the prebuilt files travel with the snapshot and nothing is rebuilt)."""
+    from cpflow_amd import build as hip_build
+    if not os.path.exists(hip_build.OUT):
+        hip_build.build(force=True)
+    if not os.path.exists(os.path.join(ROOT, 'oracle', '_build', 'libcpf_oracle.so')):
+        import oracle
+        oracle.build()
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
