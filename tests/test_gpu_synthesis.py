@@ -292,3 +292,25 @@ def test_T0_T1_all_golden_fixtures(name):
                  num_gd_iterations=0)
     best = g['params'][np.arange(len(idx)), g['regloss'].argmin(1)]
     assert (_np(ev.optimize(best))['cz'] == g['cz']).all()
+
+
+def test_integration_stub_from_the_document_runs():
+    """The ctypes stub printed in INTEGRATION.md (what a cpflow maintainer would paste) is executed as written
+    against the built library and must agree with the engine bit for bit."""
+    import re
+    from cpflow_amd import StaticOptions, _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = re.search(r'```python\n(import ctypes as C.*?)```', text, re.S).group(1)
+    code = code.replace("C.CDLL('libcpflow_amd.so')", f"C.CDLL({_ffi.LIB_PATH!r})")
+    ns = {}
+    exec(code, ns)
+    opts = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10, num_samples=10, num_gd_iterations=300)
+    layer = [[0, 1], [1, 2]]
+    raw, cz, passed = ns['generate_raw'](layer, 3, CCZ, opts)
+    eng = _engine(layer, 12, CCZ, 'xyz', num_gd_iterations=300)
+    ref = _np(eng.optimize(eng.initial_angles(0, 10)))
+    assert len(raw) == 10 and set(raw[0]) == {'params', 'loss', 'reg', 'regloss'}
+    for s in range(10):
+        assert (raw[s]['params'] == ref['params'][s]).all() and (raw[s]['regloss'] == ref['regloss'][s]).all()
+    assert (cz == ref['cz']).all() and (passed == ref['passed']).all()
