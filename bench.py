@@ -74,8 +74,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
+        # CPF_DIST_BACKEND=gloo + CPF_ONE_DEVICE=1 emulate N ranks on a single GPU (contract smoke test only)
+        if os.environ.get('CPF_ONE_DEVICE') == '1':
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('CPF_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {n_gpus} rank(s)', file=sys.stderr)
@@ -115,7 +122,7 @@ def main():
     out, summary = step()
     fence()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if world == 1 or dist.get_backend() == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -54,8 +54,12 @@ def gather_samples(local, num_samples, group=None, force_collective=False):
     slab = torch.cat(cols, dim=1) if cols else torch.empty(count, 0)
     pad = torch.zeros(cap, slab.shape[1], dtype=torch.float32, device=slab.device)
     pad[:count] = slab
-    full = torch.empty(size * cap, slab.shape[1], dtype=torch.float32, device=slab.device)
+    device = slab.device
+    if dist.get_backend(group) == 'gloo' and pad.is_cuda:      # CPU tests / single-GPU emulation of N ranks
+        pad = pad.cpu()
+    full = torch.empty(size * cap, slab.shape[1], dtype=torch.float32, device=pad.device)
     dist.all_gather_into_tensor(full, pad, group=group) if _has_into_tensor(pad) else _all_gather_list(full, pad, size, group)
+    full = full.to(device)
     rows = torch.cat([full[r * cap:r * cap + shard_range(num_samples, r, size)[1]] for r in range(size)], dim=0)
     out, col = {}, 0
     for name, w in zip(names, widths):
