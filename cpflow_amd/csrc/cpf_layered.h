@@ -14,6 +14,25 @@
 
 namespace cpf {
 
+// Diagnostic build only (-DCPF_STAMPS): per-phase cycle sums (s_memtime) of sample 0, written to out_grad[0..7].
+#ifdef CPF_STAMPS
+#define CPF_STAMP(slot)                                                                                        \
+    {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        stamp_sum[slot] += t_ - stamp_prev;                                                                    \
+        stamp_prev = t_;                                                                                       \
+    }
+#else
+#define CPF_STAMP(slot)
+#endif
+
+#ifndef CPF_UNR6
+#define CPF_UNR6 1
+#endif
+
 template <int... I> struct iseq {};
 template <int N, int... I> struct make_iseq : make_iseq<N - 1, N - 1, I...> {};
 template <int... I> struct make_iseq<0, I...> { using type = iseq<I...>; };
@@ -171,7 +190,11 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     using PL = PairList<UD...>;
     constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS;
     constexpr int LL = sizeof...(UD) / 2;
-    constexpr int UNR = (LL % 2 == 0) ? LL : 2 * LL;      // blocks per unrolled loop body (even, for buffer parity)
+    // blocks per unrolled loop body: a whole number of layers, even (record-buffer parity); for one element per
+    // lane (blocks of ~35 / ~95 instructions) a multiple of 6, so that loop back-edges — where the compiler waits
+    // for every outstanding LDS operation — come once per 6 blocks
+    constexpr int UNR2 = (LL % 2 == 0) ? LL : 2 * LL;
+    constexpr int UNR = (E == 1 && CPF_UNR6) ? ((UNR2 % 3 == 0) ? UNR2 : 3 * UNR2) : UNR2;
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
     constexpr bool MERGE = layered_merge(NQ, LW, ROT);
     // MSTORE = 1: the forward pass keeps each run's phase in LDS (8 B per lane per block) for the backward pass;
@@ -251,8 +274,13 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
 
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
+#ifdef CPF_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
     for (int it = 0; it < iters; it++) {
         const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);     // scalar load; measured free (no change without it)
+        CPF_STAMP(7)
         // ================= forward
 #pragma unroll
         for (int e = 0; e < E; e++) { st.pr[e] = (L::row_index(lane, e) == col) ? 1.f : 0.f; st.pi[e] = 0.f; }
@@ -281,11 +309,13 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                     constexpr int IP = ((J + UNR - 1) % UNR) % LL;                 // pair of the previous block
                     float (&cur)[16] = (J & 1) ? rb : ra;
                     float (&nxt)[16] = (J & 1) ? ra : rb;
+                    // next record first: an LDS read cannot be moved above the phase store by the compiler, and
+                    // issued mid-block it returns after the next block wants it (same-box A/B on config 2: 10.19 -> 10.07 ms)
+                    load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), nxt);
                     const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                         st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
                     if constexpr (STORE) ph[64 * b] = rho;
                     phase_apply<L>(st.pr[0], st.pi[0], rho, false);
-                    load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), nxt);
                     lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
 #pragma unroll
                     for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
@@ -320,6 +350,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                 }
             }
         }
+        CPF_STAMP(1)                                  // forward blocks done
         // ================= loss, penalty, best tracking
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -357,6 +388,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         }
         if (a.T == 0) break;
 
+        CPF_STAMP(2)                                  // loss phase done
         // ================= backward sweep
         {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
@@ -463,6 +495,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             for (int full = K / UNR; full > 0; full--)
                 static_for(bwd_step, typename make_iseq<UNR>::type{});
         }
+        CPF_STAMP(3)                                  // backward blocks done
         {
             float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
 #pragma unroll
@@ -488,6 +521,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         }
         lds_sync<WPS>();
 
+        CPF_STAMP(4)                                  // backward surface gates done
         // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
         const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
 #pragma unroll
@@ -508,8 +542,12 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             publish(s);
         }
         lds_sync<WPS>();
+        CPF_STAMP(5)                                  // owner phase done
     }
 
+#ifdef CPF_STAMPS
+    if (s_idx == 0 && tid == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
+#endif
     // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164)
     const int bi = (best < first) ? 1 : 0;
     float acc[3] = {0.f, 0.f, 0.f};
