@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
 DEPS = [SRC, os.path.join(HERE, 'csrc', 'cpf_device.h'), os.path.join(HERE, 'csrc', 'cpf_blocks.h'),
-        os.path.join(HERE, 'csrc', 'cpf_layered.h'), os.path.join(HERE, 'csrc', 'cpf_jit.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
+        os.path.join(HERE, 'csrc', 'cpf_layered.h'), os.path.join(HERE, 'csrc', 'cpf_split.h'), os.path.join(HERE, 'csrc', 'cpf_jit.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
 OUT = os.path.join(HERE, 'libcpflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_*_f32 with extra moves,

@@ -71,10 +71,11 @@ inline std::map<std::string, Kernel>& table() { static std::map<std::string, Ker
 inline std::mutex& table_mutex() { static std::mutex m; return m; }
 
 // Returns nullptr (and fills err) when the kernel cannot be produced.
+// split: the two-ended kernel (cpf_split.h; nq == 3, lw ignored, 128 threads) instead of the layered one.
 inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int ppt, int mstore, const std::vector<int>& ud,
-                                 std::string* err) {
+                                 std::string* err, bool split = false) {
     std::ostringstream name;
-    name << "cpf::k_cp_layered<" << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
+    name << (split ? "cpf::k_cp_split<" : "cpf::k_cp_layered<") << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
     for (int v : ud) name << ", " << v;
     name << ">";
     const std::string expr = name.str();
@@ -84,15 +85,18 @@ inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int p
     if (it != table().end()) return it->second.fn;
 
     const std::string inc = lib_dir() + "/csrc";
-    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_blocks.h") + read_file(inc + "/cpf_layered.h");
+    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_blocks.h") + read_file(inc + "/cpf_layered.h") +
+                             (split ? read_file(inc + "/cpf_split.h") : std::string());
     if (hdrs.size() < 1000) { if (err) *err = "kernel headers not found under " + inc; return nullptr; }
     // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
     std::ostringstream targs;
-    targs << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
+    if (!split) targs << nq << ", " << lw << ", ";
+    targs << rot_code << ", " << ppt << ", " << mstore;
     for (int v : ud) targs << ", " << v;
-    const std::string src = "#include \"cpf_layered.h\"\nextern \"C\" __global__ __launch_bounds__(" +
-                            std::to_string(64 << lw) + ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    cpf::layered_body<" +
-                            targs.str() + ">(a);\n}\n";
+    const std::string src = std::string(split ? "#include \"cpf_split.h\"\n" : "#include \"cpf_layered.h\"\n") +
+                            "extern \"C\" __global__ __launch_bounds__(" + std::to_string(split ? 128 : (64 << lw)) +
+                            ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    cpf::" +
+                            (split ? "split_body<" : "layered_body<") + targs.str() + ">(a);\n}\n";
     // Backend: the offline compiler as a child process by default.  hiprtc builds the same source with the
     // same flags, but on the MI355X boxes its code came out 2x slower (SGPR spills through v_writelane /
     // v_readlane, 4477 vs 3536 instructions for the 3-qubit chain kernel: 20.6 ms vs 11.0 ms on config 2);

@@ -1,0 +1,553 @@
+// cpflow_amd: the two-ended 3-qubit kernel — two waves per sample, each owning half of the circuit.
+//
+// With S <= 4 x CUs samples every SIMD holds a single wave of the one-wave kernel (cpf_layered.h), and a step is
+// one dependent chain of ~3000 issue slots with nothing to overlap its LDS / DPP / transcendental latencies.
+// The chain is cut in two.  Write U = H2 H1 with H1 = B_{m-1} .. B_0 S (surface gates and the first m blocks) and
+// H2 = B_{K-1} .. B_m.  Since  tr(V^+ H2 H1) = sum conj(W) o H1  with  W = H2^+ V :
+//
+//   forward    wave A builds psi = H1 from the identity      |  wave B builds W by un-applying blocks K-1 .. m from V
+//   exchange   psi and W through LDS (512 B each way); both waves form T, the loss and f = -T / N^2
+//   backward   wave A: C = f W, sweeps blocks m-1 .. 0 and    |  wave B: psi = H1, C = f W, sweeps blocks m .. K-1
+//              the surface gates backwards (un-applying)      |  FORWARDS (applying each gate to psi and C, then
+//                                                             |  reading its gradient: the same psi_j, C_j pair)
+//   owner      128 threads own the angles (Adam state in registers), one round for P <= 128
+//
+// Same arithmetic per gate as the one-wave kernel (merged diagonal runs, DPP rotations, reduce8 gradient
+// scatter); the differences in rounding are those of evaluating the same products in another order
+// (|d loss| <= 1e-6, tests/test_gpu_kernels.py::test_split_*).  Requires: 3 qubits, rotation string ending in
+// 'z', loss kinds with a linear cotangent (HST, state preparation), K <= 64, m a multiple of the layer length.
+#pragma once
+#include "cpf_layered.h"
+
+namespace cpf {
+
+// number of blocks given to wave A: balances (surface ~ 1.5 blocks) + m against K - m, multiple of the layer length
+__host__ __device__ constexpr int split_point(int K, int LL) {
+    int m = ((2 * K - 3 + 2 * LL) / (4 * LL)) * LL;          // LL * round((K - 1.5) / 2 / LL)
+    if (m < LL) m = LL;
+    const int top = ((K - 1) / LL) * LL;
+    if (m > top) m = top;
+    return m < 0 ? 0 : m;
+}
+__host__ __device__ constexpr bool split_supported(int K, int LL) { return K >= 2 * LL && K >= 2 && K <= 64; }
+
+struct SplitLds {                                          // float offsets; [0, 28) = penalty table
+    using B = LayeredLds<3>;
+    static constexpr int SURF_F = B::SURF_F, NBATCH = B::NBATCH, SURF_CS = B::SURF_CS, BLK_CS = B::BLK_CS;
+    __host__ __device__ static constexpr int slab(int K) { return BLK_CS + 16 * K; }              // surface batches, then 32 per block
+    __host__ __device__ static constexpr int dummy(int K) { return slab(K) + 32 * (NBATCH + K); } // sink of wave B's "block -1"
+    __host__ __device__ static constexpr int red(int K) { return dummy(K) + 32; }                  // [0] penalty sum
+    __host__ __device__ static constexpr int xch(int K) { return red(K) + 4; }                     // 2 x 64 x (re, im)
+    __host__ __device__ static constexpr int phase(int K) { return xch(K) + 256; }                 // (K + 2) units x 64 lanes x (re, im)
+    __host__ __device__ static constexpr int total(int K, bool store) { return phase(K) + (store ? 128 * (K + 2) : 0); }
+};
+
+template <int LL>
+struct SplitUnroll {
+    static constexpr int UNR2 = (LL % 2 == 0) ? LL : 2 * LL;
+    static constexpr int UNR = (UNR2 % 3 == 0) ? UNR2 : 3 * UNR2;      // even, whole layers, multiple of 6 (see cpf_layered.h)
+};
+
+// ---- wave A forward: blocks [0, n) applied to psi; units (merged diagonal runs) 0 .. n stored at ph[64 u]
+template <class L, class PL, int LL, int ROT, bool STORE>
+__device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n, float2* ph) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+    float ra[16], rb[16];
+    float pz[4] = {1.f, 0.f, 1.f, 0.f};
+    int b = 0;
+    if (n > 0) load_rec(rec, ra);
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        float (&cur)[16] = (J & 1) ? rb : ra;
+        float (&nxt)[16] = (J & 1) ? ra : rb;
+        load_rec(rec + 16 * (b + 1 < n ? b + 1 : b), nxt);
+        const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+            st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+        if constexpr (STORE) ph[64 * b] = rho;
+        phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+        lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
+#pragma unroll
+        for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
+        b++;
+    };
+    for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
+    static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
+    if (n > 0) {
+        const int jt = (n - 1) % UNR;
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) {
+                const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                    st, pz[0], pz[1], pz[2], pz[3], 1.f, 0.f);
+                if constexpr (STORE) ph[64 * n] = rho;
+                phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+            }
+        }, typename make_iseq<UNR>::type{});
+    }
+}
+
+// the inner rotations of a block, inverted, on psi only
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&r)[16]) {
+    constexpr int NR = rot_nr(ROT);
+#pragma unroll
+    for (int i = NR - 2; i >= 0; i--) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+        } else {
+            rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+        }
+    }
+}
+
+// ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
+template <class L, class PL, int LL, int ROT, bool STORE>
+__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, int n, float2* ph) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+    float ra[16], rb[16];
+    int b = n - 1;
+    load_rec(rec + 16 * b, ra);
+    {
+        const int jt = (n - 1) % UNR;
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) {
+                const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                    st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
+                if constexpr (STORE) ph[64 * n] = rho;
+                phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+            }
+        }, typename make_iseq<UNR>::type{});
+    }
+    auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
+        constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
+        lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
+        const bool has_prev = b > 0;
+        const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+            st, has_prev ? prv[4 * (NR - 1)] : 1.f, has_prev ? prv[4 * (NR - 1) + 1] : 0.f,
+            has_prev ? prv[4 * (NR - 1) + 2] : 1.f, has_prev ? prv[4 * (NR - 1) + 3] : 0.f,
+            cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+        if constexpr (STORE) ph[64 * b] = rho;
+        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+        b--;
+    };
+    const int tail = n % UNR;
+    static_for([&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        if (J < tail) {
+            load_rec(rec + 16 * b, ra);
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            blk(ic<I>{}, ic<IP>{}, ra, rb);
+        }
+    }, typename make_iseq<UNR>::type{});
+    if (b >= 0 && tail > 0) load_rec(rec + 16 * b, ra);
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        if constexpr ((JJ & 1) == 0) {
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            blk(ic<I>{}, ic<IP>{}, ra, rb);
+        } else {
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), ra);
+            blk(ic<I>{}, ic<IP>{}, rb, ra);
+        }
+    };
+    for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
+}
+
+// ---- wave A backward: blocks n-1 .. 0 un-applied from psi and C, gradients to gblk[32 b] (as cpf_layered.h)
+template <class L, class PL, int LL, int ROT, bool STORE>
+__device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, int n, const float2* ph, float* gblk,
+                                               int lane, int dst_lane) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+    if (n <= 0) return;
+    float ra[16], rb[16], d[8];
+    int b = n - 1;
+    float dzu = 0.f, dzd = 0.f;
+    load_rec(rec + 16 * b, ra);
+    {
+        const int jt = (n - 1) % UNR;
+        float2 rho = make_float2(1.f, 0.f);
+        if constexpr (STORE) rho = ph[64 * n];
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) {
+                if constexpr (!STORE)
+                    rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                        st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
+                const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+                dzu = -st.sg[PL::v[2 * I]] * w;
+                dzd = -st.sg[PL::v[2 * I + 1]] * w;
+            }
+        }, typename make_iseq<UNR>::type{});
+        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+        phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+    }
+    auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
+        constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
+        float2 rho;
+        if constexpr (STORE) rho = ph[64 * b];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = 0.f;
+        lay_block_bwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, d);
+        if constexpr (!STORE) {
+            const bool has_prev = b > 0;
+            rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                st, has_prev ? prv[4 * (NR - 1)] : 1.f, has_prev ? prv[4 * (NR - 1) + 1] : 0.f,
+                has_prev ? prv[4 * (NR - 1) + 2] : 1.f, has_prev ? prv[4 * (NR - 1) + 3] : 0.f,
+                cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+        }
+        d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
+        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+        constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
+        constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
+        d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        dzu = -st.sg[PL::v[2 * IP]] * w;
+        dzd = -st.sg[PL::v[2 * IP + 1]] * w;
+        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+        phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+        reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        b--;
+    };
+    const int tail = n % UNR;
+    static_for([&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        if (J < tail) {
+            load_rec(rec + 16 * b, ra);
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            blk(ic<I>{}, ic<IP>{}, ra, rb);
+        }
+    }, typename make_iseq<UNR>::type{});
+    if (b >= 0 && tail > 0) load_rec(rec + 16 * b, ra);
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        if constexpr ((JJ & 1) == 0) {
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            blk(ic<I>{}, ic<IP>{}, ra, rb);
+        } else {
+            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), ra);
+            blk(ic<I>{}, ic<IP>{}, rb, ra);
+        }
+    };
+    for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
+}
+
+// a rotation applied to psi and C, then its gradient (psi_j, C_j right after the gate)
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float lay_rot_fwd_grad(State<L>& st, float c, float s) {
+    rot_apply<L, KIND, Q>(st.pr, st.pi, c, s, st);
+    rot_apply<L, KIND, Q>(st.cr, st.ci, c, s, st);
+    return rot_grad<L, KIND, Q>(st);
+}
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_fwd_grad_inner(State<L>& st, const float (&r)[16], float (&d)[8]) {
+    constexpr int NR = rot_nr(ROT);
+#pragma unroll
+    for (int i = 0; i < NR - 1; i++) {
+        if (rot_kind(ROT, i) == OP_RX) {
+            d[2 * i] = lay_rot_fwd_grad<L, OP_RX, UP>(st, r[4 * i], r[4 * i + 1]); d[2 * i + 1] = lay_rot_fwd_grad<L, OP_RX, DN>(st, r[4 * i + 2], r[4 * i + 3]);
+        } else if (rot_kind(ROT, i) == OP_RY) {
+            d[2 * i] = lay_rot_fwd_grad<L, OP_RY, UP>(st, r[4 * i], r[4 * i + 1]); d[2 * i + 1] = lay_rot_fwd_grad<L, OP_RY, DN>(st, r[4 * i + 2], r[4 * i + 3]);
+        } else {
+            d[2 * i] = lay_rot_fwd_grad<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]); d[2 * i + 1] = lay_rot_fwd_grad<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]);
+        }
+    }
+}
+
+// ---- wave B backward: blocks 0 .. n-1 APPLIED to psi and C (psi = H1, C = f W on entry), gradients to gblk[32 b].
+// Unit b carries the CP of block b and the final Rz pair of block b-1, so block b-1's eight partials are complete
+// — and scattered — at unit b; the first scatter ("block -1") goes to a sink.
+template <class L, class PL, int LL, int ROT, bool STORE>
+__device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, int n, const float2* ph, float* gblk,
+                                               float* sink, int lane, int dst_lane) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+    float ra[16], rb[16], da[8], db[8];
+    float pz[4] = {1.f, 0.f, 1.f, 0.f};
+    int b = 0;
+    load_rec(rec, ra);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { da[k] = 0.f; db[k] = 0.f; }
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        float (&cur)[16] = (J & 1) ? rb : ra;
+        float (&nxt)[16] = (J & 1) ? ra : rb;
+        float (&dcur)[8] = (J & 1) ? db : da;
+        float (&dprv)[8] = (J & 1) ? da : db;
+        load_rec(rec + 16 * (b + 1 < n ? b + 1 : b), nxt);
+        float2 rho;
+        if constexpr (STORE) rho = ph[64 * b];
+        else rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                 st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
+        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);      // invariant under the run's common phase
+        phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+        phase_apply<L>(st.cr[0], st.ci[0], rho, false);
+        dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
+        dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
+        reduce8_rows(dprv, b > 0 ? gblk + 32 * (b - 1) : sink, lane, dst_lane);
+        constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
+        constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dcur[k] = 0.f;
+        dcur[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        lay_block_fwd_grad_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, dcur);
+        if constexpr (!STORE) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
+        }
+        b++;
+    };
+    for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
+    static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
+    {
+        const int jt = (n - 1) % UNR;
+        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);      // last unit: only its gradient is needed
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) {
+                float (&dl)[8] = (J & 1) ? db : da;
+                dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
+                dl[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * I + 1]] * w;
+                reduce8_rows(dl, gblk + 32 * (n - 1), lane, dst_lane);
+            }
+        }, typename make_iseq<UNR>::type{});
+    }
+}
+
+__device__ __forceinline__ void split_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int ROT, int PPT, int MSTORE, int... UD>
+__device__ __forceinline__ void split_body(const KArgs& a) {
+    using L = Lay<3, 0>;
+    using Lds = SplitLds;
+    using PL = PairList<UD...>;
+    constexpr int NQ = 3, TH = 128;
+    constexpr int LL = sizeof...(UD) / 2;
+    constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
+    constexpr bool STORE = MSTORE != 0;
+    static_assert(layered_merge(3, 0, ROT), "two-ended kernel: rotation string must end in 'z'");
+    static_assert(L::E == 1, "two-ended kernel: one element per lane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P, K = (P - NS) / NB;
+    const int m = split_point(K, LL), kb = K - m;
+    const int64_t s_idx = blockIdx.x;
+    const float* init = a.init + s_idx * P;
+    const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
+    float* out_best = a.out_params + (s_idx * 2 + 1) * P;
+    float* gs = smem + Lds::slab(K);
+    float* red = smem + Lds::red(K);
+    float2* xch = reinterpret_cast<float2*>(smem + Lds::xch(K)) + lane;                 // [0]: psi of wave A, [64]: W of wave B
+    float2* ph = reinterpret_cast<float2*>(smem + Lds::phase(K)) + lane + (wave ? 64 * (m + 1) : 0);
+
+    State<L> st;
+#pragma unroll
+    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; }
+    const int col = L::col_index(lane, 0);
+    const float2 vt = a.target[L::row_index(lane, 0) * L::D + col];
+    const int dst_lane = (lane & 7) * 4 + (lane >> 4);
+
+    // ---- owner state.  Owner slot o = tid + 128 s; the K <= 64 CP angles come first (all in wave 0, slot 0).
+    float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
+    int cs_off[PPT], g_off[PPT], pj[PPT];
+    bool valid[PPT], is_cp[PPT], frz[PPT];
+    penalty_table_init(smem, a, tid);
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        const int o = tid + TH * s;
+        valid[s] = o < P;
+        int j = 0;
+        if (valid[s]) {
+            if (o < K) j = NS + NB * o + NB - 1;
+            else if (o - K < NS) j = o - K;
+            else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+        }
+        pj[s] = j;
+        is_cp[s] = valid[s] && a.pkind[j];
+        frz[s] = valid[s] && frozen && frozen[j];
+        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
+        else {
+            const int b = (j - NS) / NB, k = (j - NS) % NB;
+            cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
+        }
+        th[s] = valid[s] ? init[j] : 0.f;
+        mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
+        if (valid[s]) { a.out_params[(s_idx * 2) * P + j] = th[s]; out_best[j] = th[s]; }
+    }
+    for (int b = tid; b < K; b += TH) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
+    auto publish = [&](int s) __attribute__((always_inline)) {
+        const bool pen = a.use_reg && (K > TH * s) && is_cp[s];
+        const bool lin = pen && a.pen_kind == 0;
+        float x = 0.f;
+        float2 si = make_float2(0.f, 0.f);
+        if (lin) { x = floor_mod_2pi(th[s]); si = penalty_lookup(smem, x); }
+        float sn, cn;
+        sincosf(is_cp[s] ? th[s] : 0.5f * th[s], &sn, &cn);
+        if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
+        if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
+        else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
+    };
+    // penalty sum of the CP angles (all owned by wave 0, slot 0), handed to both waves through LDS
+    auto publish_penalty = [&]() __attribute__((always_inline)) {
+        if (wave == 0 && a.use_reg) { const float p = wave_sum(pval[0]); red[0] = p; }
+    };
+    split_barrier();
+#pragma unroll
+    for (int s = 0; s < PPT; s++) publish(s);
+    publish_penalty();
+    split_barrier();
+
+    float best = 0.f, first = 0.f;
+    const int iters = a.T > 0 ? a.T : 1;
+#ifdef CPF_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
+    for (int it = 0; it < iters; it++) {
+        const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
+        const float pen_sum = a.use_reg ? red[0] : 0.f;
+        CPF_STAMP(7)
+        // ================= forward: A builds H1 from the identity, B builds W = H2^+ V
+        if (wave == 0) {
+            st.pr[0] = (L::row_index(lane, 0) == col) ? 1.f : 0.f; st.pi[0] = 0.f;
+            float sr[Lds::SURF_F];
+#pragma unroll
+            for (int i = 0; i < Lds::SURF_F / 4; i++) {
+                const float4 v = reinterpret_cast<const float4*>(smem + Lds::SURF_CS)[i];
+                sr[4 * i] = v.x; sr[4 * i + 1] = v.y; sr[4 * i + 2] = v.z; sr[4 * i + 3] = v.w;
+            }
+            static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
+                constexpr int Q = decltype(qq)::value;
+                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q], sr[6 * Q + 1], st);
+                rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
+                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
+            }, typename make_iseq<NQ>::type{});
+            split_fwd<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph);
+            xch[0] = make_float2(st.pr[0], st.pi[0]);
+        } else {
+            st.pr[0] = vt.x; st.pi[0] = vt.y;
+            split_inv<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph);
+            xch[64] = make_float2(st.pr[0], st.pi[0]);
+        }
+        CPF_STAMP(0)                                  // forward half done
+        split_barrier();
+        CPF_STAMP(1)                                  // waited for the other wave
+        // ================= loss (both waves, identical arithmetic), best tracking
+        float wr, wi;
+        if (wave == 0) { const float2 o = xch[64]; wr = o.x; wi = o.y; }
+        else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; }
+        float tr = fmaf(st.pi[0], wi, st.pr[0] * wr), ti = fmaf(-st.pr[0], wi, st.pi[0] * wr);     // T = sum psi conj(W)
+        tr = wave_sum(tr);
+        ti = wave_sum(ti);
+        const float reg = a.use_reg ? a.r * pen_sum : 0.f;
+        const float ab = sqrtf(fmaf(tr, tr, ti * ti));
+        const float loss = 1.f - ab * ab * a.inv_dim2;
+        const float regloss = loss + reg;
+        bool improved = false;
+        if (it == 0) { first = regloss; best = regloss; }
+        else if (regloss < best) { best = regloss; improved = true; }
+        if (improved) {
+#pragma unroll
+            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+        }
+        if (a.hist_params) {
+#pragma unroll
+            for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + pj[s]] = th[s];
+            if (tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
+        }
+        if (a.T == 0) break;
+        CPF_STAMP(2)                                  // loss phase done
+
+        // ================= backward: C = f W at the cut
+        {
+            const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
+            st.cr[0] = fmaf(fr, wr, -fi * wi);
+            st.ci[0] = fmaf(fr, wi, fi * wr);
+        }
+        if (wave == 0) {
+            split_bwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph, gs + 32 * Lds::NBATCH, lane, dst_lane);
+            float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
+#pragma unroll
+            for (int i = 0; i < Lds::SURF_F / 4; i++) {
+                const float4 v = reinterpret_cast<const float4*>(smem + Lds::SURF_CS)[i];
+                sr[4 * i] = v.x; sr[4 * i + 1] = v.y; sr[4 * i + 2] = v.z; sr[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8 * Lds::NBATCH; k++) ds[k] = 0.f;
+            static_for([&](auto qq) __attribute__((always_inline)) {
+                constexpr int Q = NQ - 1 - decltype(qq)::value;
+                ds[3 * Q + 2] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q + 4], sr[6 * Q + 5]);
+                ds[3 * Q + 1] = lay_rot_bwd<L, OP_RX, Q>(st, sr[6 * Q + 2], sr[6 * Q + 3]);
+                ds[3 * Q + 0] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q], sr[6 * Q + 1]);
+            }, typename make_iseq<NQ>::type{});
+#pragma unroll
+            for (int bt = 0; bt < Lds::NBATCH; bt++) {
+                float d8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d8[k] = ds[8 * bt + k];
+                reduce8_rows(d8, gs + 32 * bt, lane, dst_lane);
+            }
+        } else {
+            split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
+                                                  smem + Lds::dummy(K), lane, dst_lane);
+        }
+        CPF_STAMP(3)                                  // backward half done
+        split_barrier();
+        CPF_STAMP(4)                                  // waited for the other wave
+
+        // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            const float4 gp = *reinterpret_cast<const float4*>(gs + g_off[s]);
+            float g = (gp.x + gp.y) + (gp.z + gp.w);
+            if (a.use_reg && is_cp[s]) g += psl[s];
+            if (valid[s] && !frz[s]) {
+                const float mo = fmaf(a.b1, mm[s], a.omb1 * g);
+                const float v = fmaf(a.b2, vv[s], a.omb2 * (g * g));
+                mm[s] = mo; vv[s] = v;
+                th[s] = fmaf(-a.lr, (mo * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[s]);
+            }
+            publish(s);
+        }
+        publish_penalty();
+        CPF_STAMP(5)                                  // owner phase done
+        split_barrier();
+        CPF_STAMP(6)
+    }
+#ifdef CPF_STAMPS
+    if (s_idx == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 * wave + k] = (float)stamp_sum[k];
+#endif
+
+    // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164): CP owners all sit in wave 0
+    if (wave == 0) {
+        const int bi = (best < first) ? 1 : 0;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (is_cp[0]) {
+            const int j = pj[0];
+            const float t0 = a.out_params[(s_idx * 2) * P + j], t1 = out_best[j];
+            float sl;
+            if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
+            acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+        if (tid == 0) {
+            const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
+            const float l0 = first - reg0, l1 = best - reg1;
+            a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
+            a.out_reg[s_idx * 2 + 0] = reg0;      a.out_reg[s_idx * 2 + 1] = reg1;
+            a.out_loss[s_idx * 2 + 0] = l0;       a.out_loss[s_idx * 2 + 1] = l1;
+            a.out_cz[s_idx] = (int32_t)acc[2];
+            a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
+        }
+    }
+}
+
+template <int ROT, int PPT, int MSTORE, int... UD>
+__global__ __launch_bounds__(128, 1) void k_cp_split(const KArgs a) {
+    split_body<ROT, PPT, MSTORE, UD...>(a);
+}
+
+}  // namespace cpf

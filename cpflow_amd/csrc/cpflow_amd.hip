@@ -16,6 +16,7 @@
 #include "cpf_device.h"
 #include "cpf_blocks.h"
 #include "cpf_layered.h"
+#include "cpf_split.h"
 #include "cpf_jit.h"
 
 namespace {
@@ -137,8 +138,24 @@ bool phases_fit(int num_cu, int64_t S, size_t lds_bytes_with_phases) {
     const int64_t want = std::min<int64_t>((S + num_cu - 1) / num_cu, 20);
     return (int64_t)(160 * 1024 / lds_bytes_with_phases) >= want;
 }
+// Two waves per sample (cpf_split.h) while the one-wave kernel would leave SIMDs with a single wave: the step is
+// then one exposed dependent chain, and cutting it in two is worth more than the second wave's issue slots.
+bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int rot_code, int64_t S) {
+    if (!cpf::layered_merge(3, 0, rot_code) || !cpf::split_supported(K, LL) || a.loss_kind == 2) return false;
+    { const char* e = getenv("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
+    return S <= (int64_t)plan->num_cu * 4;
+}
 template <int ROT, int PPT, int... UD>
-int launch_layered3(const cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
+    plan->variant = "layered/aot waves=1";
+    if (want_split(plan, a, K, (int)sizeof...(UD) / 2, ROT, S)) {
+        const size_t lds = (size_t)cpf::SplitLds::total(K, true) * sizeof(float);
+        hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT / 2, 1, UD...>), dim3((unsigned)S), dim3(128), lds, stream, a);
+        CPF_HIP(hipGetLastError());
+        plan->variant = "split/aot waves=2";
+        return 0;
+    }
     const bool merge = cpf::layered_merge(3, 0, ROT);
     const size_t lds1 = (size_t)cpf::LayeredLds<3>::total(K, 1, merge) * sizeof(float);
     const size_t lds0 = (size_t)cpf::LayeredLds<3>::total(K, 1, false) * sizeof(float);
@@ -213,6 +230,21 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     const int rot_code = cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]);
     size_t lds = 0;
     int mstore = 0;
+    if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S)) {
+        const int sppt = (a.P + 127) / 128;
+        const size_t slds = (size_t)cpf::SplitLds::total(plan->K, true) * sizeof(float);
+        std::string serr;
+        hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, 1, plan->layer_ud, &serr, true) : nullptr;
+        if (sfn) {
+            cpf::KArgs args = a;
+            void* params[] = {&args};
+            const hipError_t e = hipModuleLaunchKernel(sfn, (unsigned)S, 1, 1, 128, 1, 1, (unsigned)slds, stream, params, nullptr);
+            *rc = e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+            plan->variant = "split/jit waves=2";
+            return true;
+        }
+        plan->jit_note = serr;          // fall through to the one-wave kernel
+    }
     if (plan->NQ == 3 && cpf::layered_merge(3, lw, rot_code)) {
         const size_t with = (size_t)cpf::LayeredLds<3>::total(plan->K, 1, true) * sizeof(float);
         mstore = (with <= 64 * 1024 && phases_fit(plan->num_cu, S, with)) ? 1 : 0;
@@ -232,6 +264,7 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     cpf::KArgs args = a;
     void* params[] = {&args};
     const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
+    plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1");
     if (e != hipSuccess) { *rc = fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e)); return true; }
     *rc = 0;
     return true;
@@ -246,7 +279,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     int rc = 0;
     // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
     // kernel; 3. generic per-gate kernel
-    if (try_layered3_aot(plan, a, S, stream, &rc)) { plan->variant = "layered/aot waves=1"; return rc; }
+    if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     const int64_t simds = (int64_t)plan->num_cu * 4;
     // waves per sample: 1 when there are enough samples to fill the SIMDs, else 4 (columns split over waves)
     int lw = 0;
@@ -260,7 +293,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
-    if (try_layered_jit(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1"); return rc; }
+    if (try_layered_jit(plan, a, lw, S, stream, &rc)) return rc;
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
     switch (plan->NQ) {
         case 3: return launch_variant<3, 0>(a, S, stream);
