@@ -181,6 +181,25 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
     gate_fence<L>();
 }
 
+// The surface gates, backwards.  Gates on different qubits commute, so each qubit's Rz Rx Rz is differentiated
+// from the state after the WHOLE surface layer, un-applying only that qubit's own gates: independent chains
+// (instruction-level parallelism for a lone wave), two un-applications per qubit instead of three, and the
+// product conj(C) psi of the three final Rz gradients is shared.  Small tiles only: each chain works on a copy.
+template <class L, int NQ, int SF, int ND>
+__device__ __forceinline__ void surface_bwd_independent(const State<L>& st, const float (&sr)[SF], float (&ds)[ND]) {
+    static_for([&](auto qq) __attribute__((always_inline)) {
+        constexpr int Q = decltype(qq)::value;
+        State<L> s = st;
+        ds[3 * Q + 2] = rot_grad<L, OP_RZ, Q>(s);
+        rot_apply<L, OP_RZ, Q>(s.pr, s.pi, sr[6 * Q + 4], -sr[6 * Q + 5], s);
+        rot_apply<L, OP_RZ, Q>(s.cr, s.ci, sr[6 * Q + 4], -sr[6 * Q + 5], s);
+        ds[3 * Q + 1] = rot_grad<L, OP_RX, Q>(s);
+        rot_apply<L, OP_RX, Q>(s.pr, s.pi, sr[6 * Q + 2], -sr[6 * Q + 3], s);
+        rot_apply<L, OP_RX, Q>(s.cr, s.ci, sr[6 * Q + 2], -sr[6 * Q + 3], s);
+        ds[3 * Q + 0] = rot_grad<L, OP_RZ, Q>(s);
+    }, typename make_iseq<NQ>::type{});
+}
+
 // UD... = up0, dn0, up1, dn1, ...: the layer (topology.py:15-20: block b sits on pair b mod len)
 // MSTORE: see STORE below (only meaningful when layered_merge(NQ, LW, ROT))
 template <int NQ, int LW, int ROT, int PPT, int MSTORE, int... UD>
@@ -505,12 +524,16 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             }
 #pragma unroll
             for (int k = 0; k < 8 * Lds::NBATCH; k++) ds[k] = 0.f;
-            static_for([&](auto qq) __attribute__((always_inline)) {
-                constexpr int Q = NQ - 1 - decltype(qq)::value;
-                ds[3 * Q + 2] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q + 4], sr[6 * Q + 5]);
-                ds[3 * Q + 1] = lay_rot_bwd<L, OP_RX, Q>(st, sr[6 * Q + 2], sr[6 * Q + 3]);
-                ds[3 * Q + 0] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q], sr[6 * Q + 1]);
-            }, typename make_iseq<NQ>::type{});
+            if constexpr (E <= 4) {
+                surface_bwd_independent<L, NQ>(st, sr, ds);
+            } else {
+                static_for([&](auto qq) __attribute__((always_inline)) {
+                    constexpr int Q = NQ - 1 - decltype(qq)::value;
+                    ds[3 * Q + 2] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q + 4], sr[6 * Q + 5]);
+                    ds[3 * Q + 1] = lay_rot_bwd<L, OP_RX, Q>(st, sr[6 * Q + 2], sr[6 * Q + 3]);
+                    ds[3 * Q + 0] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q], sr[6 * Q + 1]);
+                }, typename make_iseq<NQ>::type{});
+            }
 #pragma unroll
             for (int bt = 0; bt < Lds::NBATCH; bt++) {
                 float d8[8];

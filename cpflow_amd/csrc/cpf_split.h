@@ -388,14 +388,11 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
         else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
     };
-    // penalty sum of the CP angles (all owned by wave 0, slot 0), handed to both waves through LDS
-    auto publish_penalty = [&]() __attribute__((always_inline)) {
-        if (wave == 0 && a.use_reg) { const float p = wave_sum(pval[0]); red[0] = p; }
-    };
+    // penalty sum of the CP angles (all owned by wave 0, slot 0): wave A reduces it at the top of its forward half
+    // (where it has slack against wave B) and hands it to wave B through LDS before the exchange barrier
     split_barrier();
 #pragma unroll
     for (int s = 0; s < PPT; s++) publish(s);
-    publish_penalty();
     split_barrier();
 
     float best = 0.f, first = 0.f;
@@ -406,10 +403,11 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
 #endif
     for (int it = 0; it < iters; it++) {
         const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
-        const float pen_sum = a.use_reg ? red[0] : 0.f;
+        float pen_sum = 0.f;
         CPF_STAMP(7)
         // ================= forward: A builds H1 from the identity, B builds W = H2^+ V
         if (wave == 0) {
+            if (a.use_reg) { pen_sum = wave_sum(pval[0]); red[0] = pen_sum; }
             st.pr[0] = (L::row_index(lane, 0) == col) ? 1.f : 0.f; st.pi[0] = 0.f;
             float sr[Lds::SURF_F];
 #pragma unroll
@@ -436,7 +434,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         // ================= loss (both waves, identical arithmetic), best tracking
         float wr, wi;
         if (wave == 0) { const float2 o = xch[64]; wr = o.x; wi = o.y; }
-        else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; }
+        else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; if (a.use_reg) pen_sum = red[0]; }
         float tr = fmaf(st.pi[0], wi, st.pr[0] * wr), ti = fmaf(-st.pr[0], wi, st.pi[0] * wr);     // T = sum psi conj(W)
         tr = wave_sum(tr);
         ti = wave_sum(ti);
@@ -475,12 +473,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
 #pragma unroll
             for (int k = 0; k < 8 * Lds::NBATCH; k++) ds[k] = 0.f;
-            static_for([&](auto qq) __attribute__((always_inline)) {
-                constexpr int Q = NQ - 1 - decltype(qq)::value;
-                ds[3 * Q + 2] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q + 4], sr[6 * Q + 5]);
-                ds[3 * Q + 1] = lay_rot_bwd<L, OP_RX, Q>(st, sr[6 * Q + 2], sr[6 * Q + 3]);
-                ds[3 * Q + 0] = lay_rot_bwd<L, OP_RZ, Q>(st, sr[6 * Q], sr[6 * Q + 1]);
-            }, typename make_iseq<NQ>::type{});
+            surface_bwd_independent<L, NQ>(st, sr, ds);
 #pragma unroll
             for (int bt = 0; bt < Lds::NBATCH; bt++) {
                 float d8[8];
@@ -511,7 +504,6 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
             publish(s);
         }
-        publish_penalty();
         CPF_STAMP(5)                                  // owner phase done
         split_barrier();
         CPF_STAMP(6)

@@ -23,7 +23,7 @@ T = int(os.environ.get('T', '2000'))
 for name in (sys.argv[1:] or ['cfg2']):
     layer, K, tgt, Ss = CFG[name]
     eng = TemplateEngine(layer, K, tgt, 'xyz', num_gd_iterations=T)
-    for S in Ss:
+    for S in (Ss[:1] if os.environ.get('FIRST') else Ss):
         init = eng.initial_angles(0, S)
         out = eng.optimize(init); torch.cuda.synchronize()
         ms = []
