@@ -37,7 +37,8 @@ struct SplitLds {                                          // float offsets; [0,
     __host__ __device__ static constexpr int slab(int K) { return BLK_CS + 16 * K; }              // surface batches, then 32 per block
     __host__ __device__ static constexpr int dummy(int K) { return slab(K) + 32 * (NBATCH + K); } // sink of wave B's "block -1"
     __host__ __device__ static constexpr int red(int K) { return dummy(K) + 32; }                  // [0] penalty sum
-    __host__ __device__ static constexpr int xch(int K) { return red(K) + 4; }                     // 2 x 64 x (re, im)
+    __host__ __device__ static constexpr int ident(int K) { return red(K) + 4; }                   // record of identity gates ("block -1")
+    __host__ __device__ static constexpr int xch(int K) { return ident(K) + 16; }                  // 2 x 64 x (re, im)
     __host__ __device__ static constexpr int phase(int K) { return xch(K) + 256; }                 // (K + 2) units x 64 lanes x (re, im)
     __host__ __device__ static constexpr int total(int K, bool store) { return phase(K) + (store ? 128 * (K + 2) : 0); }
 };
@@ -104,7 +105,7 @@ __device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&
 
 // ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
 template <class L, class PL, int LL, int ROT, bool STORE>
-__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, int n, float2* ph) {
+__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, float2* ph) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
     float ra[16], rb[16];
     int b = n - 1;
@@ -124,10 +125,8 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, int n,
     auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
         constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
         lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
-        const bool has_prev = b > 0;
         const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
-            st, has_prev ? prv[4 * (NR - 1)] : 1.f, has_prev ? prv[4 * (NR - 1) + 1] : 0.f,
-            has_prev ? prv[4 * (NR - 1) + 2] : 1.f, has_prev ? prv[4 * (NR - 1) + 3] : 0.f,
+            st, prv[4 * (NR - 1)], prv[4 * (NR - 1) + 1], prv[4 * (NR - 1) + 2], prv[4 * (NR - 1) + 3],
             cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
         if constexpr (STORE) ph[64 * b] = rho;
         phase_apply<L>(st.pr[0], st.pi[0], rho, true);
@@ -138,7 +137,7 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, int n,
         constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
         if (J < tail) {
             load_rec(rec + 16 * b, ra);
-            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
             blk(ic<I>{}, ic<IP>{}, ra, rb);
         }
     }, typename make_iseq<UNR>::type{});
@@ -146,10 +145,10 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, int n,
     auto step = [&](auto jj) __attribute__((always_inline)) {
         constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
         if constexpr ((JJ & 1) == 0) {
-            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), rb);
+            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
             blk(ic<I>{}, ic<IP>{}, ra, rb);
         } else {
-            load_rec(rec + 16 * (b > 0 ? b - 1 : 0), ra);
+            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, ra);
             blk(ic<I>{}, ic<IP>{}, rb, ra);
         }
     };
@@ -376,6 +375,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         if (valid[s]) { a.out_params[(s_idx * 2) * P + j] = th[s]; out_best[j] = th[s]; }
     }
     for (int b = tid; b < K; b += TH) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
+    if (tid < 16) smem[Lds::ident(K) + tid] = (tid & 1) ? 0.f : 1.f;
     auto publish = [&](int s) __attribute__((always_inline)) {
         const bool pen = a.use_reg && (K > TH * s) && is_cp[s];
         const bool lin = pen && a.pen_kind == 0;
@@ -425,7 +425,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             xch[0] = make_float2(st.pr[0], st.pi[0]);
         } else {
             st.pr[0] = vt.x; st.pi[0] = vt.y;
-            split_inv<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph);
+            split_inv<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph);
             xch[64] = make_float2(st.pr[0], st.pi[0]);
         }
         CPF_STAMP(0)                                  // forward half done

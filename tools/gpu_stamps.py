@@ -1,11 +1,11 @@
 """Diagnostic: per-phase cycle shares of the layered kernel (library built with -DCPF_STAMPS, see cpf_layered.h)."""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from cpflow_amd.engine import TemplateEngine
 CCZ = np.diag([1,1,1,1,1,1,1,-1]).astype(complex)
 T = 500
 eng = TemplateEngine([[0,1],[1,2]], 12, CCZ, 'xyz', num_gd_iterations=T)
-init = eng.initial_angles(0, 1024)
+init = eng.initial_angles(0, int(os.environ.get('S', '1024')))
 out = eng.optimize(init, keep_history=True)
 if eng.last_variant().startswith('split'):
     h = out['history_regloss'][0, :16].cpu().numpy().astype(np.float64)
