@@ -156,6 +156,17 @@ __device__ __forceinline__ float wave_sum(float x) {
     x += dpp<0x143, 0xC, 0xF>(0.f, x);                       // row_bcast:31 into rows 2,3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+// two sums at once: the stages of the two reductions alternate, so each fills the other's DPP wait states
+__device__ __forceinline__ void wave_sum2(float& x, float& y) {
+    x += dppz<0xB1>(x);  y += dppz<0xB1>(y);
+    x += dppz<0x4E>(x);  y += dppz<0x4E>(y);
+    x += dppz<0x124>(x); y += dppz<0x124>(y);
+    x += dppz<0x128>(x); y += dppz<0x128>(y);
+    x += dpp<0x142, 0xA, 0xF>(0.f, x); y += dpp<0x142, 0xA, 0xF>(0.f, y);
+    x += dpp<0x143, 0xC, 0xF>(0.f, x); y += dpp<0x143, 0xC, 0xF>(0.f, y);
+    x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));
+}
 
 // ------------------------------------------------------------------ per-thread state
 template <class L>

