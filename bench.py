@@ -135,7 +135,7 @@ def main():
         alg_bytes = S_local * (8 * P + 28) + 8 * 8 * 8         # persistent model: theta0 in, best theta + scalars out
         traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_v3_pmc_summary.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01_v4_pmc_summary.json')) as f:
                 traffic = json.load(f)['traffic_bytes_per_launch'] if S_local == 1024 else None
         except Exception:
             pass
@@ -150,7 +150,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tf / FP32_PEAK_TFLOPS, 'traffic': traffic,
                          'note': 'fp32 vector ALU work (no MFMA used); peak = f32 vector = f32 MFMA dense peak; '
-                                 f'kernel {k_ms:.3f} ms per launch (HIP events), {flops:.0f} flop/sample-step'},
+                                 f'kernel {k_ms:.3f} ms per launch (HIP events), {flops:.0f} flop/sample-step',
+                         'kernel': eng.last_variant()},
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes,
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,
                     'frac': alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

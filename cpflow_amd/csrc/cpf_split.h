@@ -35,8 +35,7 @@ struct SplitLds {                                          // float offsets; [0,
     using B = LayeredLds<3>;
     static constexpr int SURF_F = B::SURF_F, NBATCH = B::NBATCH, SURF_CS = B::SURF_CS, BLK_CS = B::BLK_CS;
     __host__ __device__ static constexpr int slab(int K) { return BLK_CS + 16 * K; }              // surface batches, then 32 per block
-    __host__ __device__ static constexpr int dummy(int K) { return slab(K) + 32 * (NBATCH + K); } // sink of wave B's "block -1"
-    __host__ __device__ static constexpr int red(int K) { return dummy(K) + 32; }                  // [0] penalty sum
+    __host__ __device__ static constexpr int red(int K) { return slab(K) + 32 * (NBATCH + K); }    // [0] penalty sum, [1] "best so far" flag
     __host__ __device__ static constexpr int ident(int K) { return red(K) + 4; }                   // record of identity gates ("block -1")
     __host__ __device__ static constexpr int xch(int K) { return ident(K) + 16; }                  // 2 x 64 x (re, im)
     __host__ __device__ static constexpr int phase(int K) { return xch(K) + 256; }                 // (K + 2) units x 64 lanes x (re, im)
@@ -256,10 +255,10 @@ __device__ __forceinline__ void lay_block_fwd_grad_inner(State<L>& st, const flo
 
 // ---- wave B backward: blocks 0 .. n-1 APPLIED to psi and C (psi = H1, C = f W on entry), gradients to gblk[32 b].
 // Unit b carries the CP of block b and the final Rz pair of block b-1, so block b-1's eight partials are complete
-// — and scattered — at unit b; the first scatter ("block -1") goes to a sink.
+// — and scattered — at unit b.
 template <class L, class PL, int LL, int ROT, bool STORE>
 __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, int n, const float2* ph, float* gblk,
-                                               float* sink, int lane, int dst_lane) {
+                                               int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
     float ra[16], rb[16], da[8], db[8];
     float pz[4] = {1.f, 0.f, 1.f, 0.f};
@@ -283,7 +282,7 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
         phase_apply<L>(st.cr[0], st.ci[0], rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
-        reduce8_rows(dprv, b > 0 ? gblk + 32 * (b - 1) : sink, lane, dst_lane);
+        if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
         constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
         constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
 #pragma unroll
@@ -437,21 +436,26 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; if (a.use_reg) pen_sum = red[0]; }
         float tr = fmaf(st.pi[0], wi, st.pr[0] * wr), ti = fmaf(-st.pr[0], wi, st.pi[0] * wr);     // T = sum psi conj(W)
         wave_sum2(tr, ti);
-        const float reg = a.use_reg ? a.r * pen_sum : 0.f;
-        const float ab = sqrtf(fmaf(tr, tr, ti * ti));
-        const float loss = 1.f - ab * ab * a.inv_dim2;
-        const float regloss = loss + reg;
+        // wave A alone turns T into the loss and tracks the best iterate; wave B needs only T (for the cotangent)
+        // and, at its owner phase, A's verdict on whether this iterate is the best so far (red[1])
         bool improved = false;
-        if (it == 0) { first = regloss; best = regloss; }
-        else if (regloss < best) { best = regloss; improved = true; }
-        if (improved) {
+        if (wave == 0) {
+            const float reg = a.use_reg ? a.r * pen_sum : 0.f;
+            const float ab = sqrtf(fmaf(tr, tr, ti * ti));
+            const float loss = 1.f - ab * ab * a.inv_dim2;
+            const float regloss = loss + reg;
+            if (it == 0) { first = regloss; best = regloss; }
+            else if (regloss < best) { best = regloss; improved = true; }
+            red[1] = improved ? 1.f : 0.f;
+            if (improved) {
 #pragma unroll
-            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+                for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+            }
+            if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         }
         if (a.hist_params) {
 #pragma unroll
             for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + pj[s]] = th[s];
-            if (tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         }
         if (a.T == 0) break;
         CPF_STAMP(2)                                  // loss phase done
@@ -482,13 +486,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
         } else {
             split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
-                                                  smem + Lds::dummy(K), lane, dst_lane);
+                                                  lane, dst_lane);
         }
         CPF_STAMP(3)                                  // backward half done
         split_barrier();
         CPF_STAMP(4)                                  // waited for the other wave
 
         // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
+        if (wave != 0 && red[1] != 0.f) {              // best iterate so far (decided by wave A): keep the pre-update angles
+#pragma unroll
+            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+        }
         const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
