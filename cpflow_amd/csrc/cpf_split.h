@@ -39,7 +39,13 @@ struct SplitLds {                                          // float offsets; [0,
     __host__ __device__ static constexpr int ident(int K) { return red(K) + 4; }                   // record of identity gates ("block -1")
     __host__ __device__ static constexpr int xch(int K) { return ident(K) + 16; }                  // 2 x 64 x (re, im)
     __host__ __device__ static constexpr int phase(int K) { return xch(K) + 256; }                 // (K + 2) units x 64 lanes x (re, im)
-    __host__ __device__ static constexpr int total(int K, bool store) { return phase(K) + (store ? 128 * (K + 2) : 0); }
+    // stored states (MSTORE = 2): 64 lanes x (re, im) per slot.  Wave A: slot 0 = psi after the surface gates, slot
+    // 1 + NI b + g = psi after inner gate g of block b (NI = inner gates per block); wave B likewise for W with its
+    // slot 0 unused (W at the cut stays in registers): NI K + 2 slots in all.
+    __host__ __device__ static constexpr int states(int K) { return phase(K) + 128 * (K + 2); }
+    __host__ __device__ static constexpr int total(int K, int mstore, int ni = 0) {
+        return mstore == 2 ? states(K) + 128 * (ni * K + 2) : phase(K) + (mstore ? 128 * (K + 2) : 0);
+    }
 };
 
 template <int LL>
@@ -48,10 +54,39 @@ struct SplitUnroll {
     static constexpr int UNR = (UNR2 % 3 == 0) ? UNR2 : 3 * UNR2;      // even, whole layers, multiple of 6 (see cpf_layered.h)
 };
 
+// inner gate g of a block (application order: letter 0 on up, letter 0 on dn, letter 1 on up, ...; the final
+// letter's pair belongs to the merged diagonal run): kind, qubit and the (cos, sin) slot of the block record
+template <int ROT, int G> struct InnerGate {
+    static constexpr int LETTER = G / 2, KIND = rot_kind(ROT, LETTER), CS = 4 * LETTER + 2 * (G & 1);
+    template <int UP, int DN> static constexpr int qubit() { return (G & 1) ? DN : UP; }
+};
+template <int ROT> __host__ __device__ constexpr int inner_gates() { return 2 * (rot_nr(ROT) - 1); }
+
+// forward inner rotations of a block on psi, psi stored after each gate: slot[64 g]
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_fwd_inner_store(State<L>& st, const float (&r)[16], float2* slot) {
+    static_for([&](auto gg) __attribute__((always_inline)) {
+        constexpr int G = decltype(gg)::value;
+        using IG = InnerGate<ROT, G>;
+        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.pr, st.pi, r[IG::CS], r[IG::CS + 1], st);
+        slot[64 * G] = make_float2(st.pr[0], st.pi[0]);
+    }, typename make_iseq<inner_gates<ROT>()>::type{});
+}
+// inverse inner rotations of a block on psi, psi stored BEFORE each un-application (= the state after that gate)
+template <class L, int UP, int DN, int ROT>
+__device__ __forceinline__ void lay_block_inv_inner_store(State<L>& st, const float (&r)[16], float2* slot) {
+    static_for([&](auto gg) __attribute__((always_inline)) {
+        constexpr int G = inner_gates<ROT>() - 1 - decltype(gg)::value;
+        using IG = InnerGate<ROT, G>;
+        slot[64 * G] = make_float2(st.pr[0], st.pi[0]);
+        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.pr, st.pi, r[IG::CS], -r[IG::CS + 1], st);
+    }, typename make_iseq<inner_gates<ROT>()>::type{});
+}
+
 // ---- wave A forward: blocks [0, n) applied to psi; units (merged diagonal runs) 0 .. n stored at ph[64 u]
-template <class L, class PL, int LL, int ROT, bool STORE>
-__device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n, float2* ph) {
-    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false>
+__device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n, float2* ph, float2* sp = nullptr) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     float ra[16], rb[16];
     float pz[4] = {1.f, 0.f, 1.f, 0.f};
     int b = 0;
@@ -65,7 +100,8 @@ __device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n,
             st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
         if constexpr (STORE) ph[64 * b] = rho;
         phase_apply<L>(st.pr[0], st.pi[0], rho, false);
-        lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
+        if constexpr (PS) lay_block_fwd_inner_store<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, sp + 64 * (NI * b + 1));
+        else lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
 #pragma unroll
         for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
         b++;
@@ -103,9 +139,9 @@ __device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&
 }
 
 // ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
-template <class L, class PL, int LL, int ROT, bool STORE>
-__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, float2* ph) {
-    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
+template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false>
+__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, float2* ph, float2* sp = nullptr) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     float ra[16], rb[16];
     int b = n - 1;
     load_rec(rec + 16 * b, ra);
@@ -123,7 +159,8 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
     }
     auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
         constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
-        lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
+        if constexpr (PS) lay_block_inv_inner_store<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, sp + 64 * (NI * b + 1));
+        else lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
         const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
             st, prv[4 * (NR - 1)], prv[4 * (NR - 1) + 1], prv[4 * (NR - 1) + 2], prv[4 * (NR - 1) + 3],
             cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
@@ -312,6 +349,146 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
     }
 }
 
+// ================= stored-state sweeps (MSTORE = 2) =====================================================
+// The forward halves keep psi (wave A) / W (wave B) after every inner gate in LDS, so the gradient halves move ONE
+// matrix per gate instead of two: wave A un-applies gates from C only and reads psi_j back; wave B applies gates to
+// psi' = conj(f) H1 only and reads W_j back (Im(conj(f W) s psi) = Im(conj(W) s conj(f) psi): the scalar f moves
+// onto psi once).  Per block 4 x (4 + 3) + 13 VALU operations instead of 4 x (8 + 3) + 15, for NI + 1 more
+// ds_read_b64 / NI more ds_write_b64, prefetched one block ahead; no float32 drift from un-applying psi.
+template <int NI>
+struct BlkBuf { float r[16]; float2 x[NI > 0 ? NI : 1]; float2 rho; };
+template <int NI>
+__device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const float2* slots, const float2* ph) {
+    load_rec(rec, q.r);
+#pragma unroll
+    for (int j = 0; j < NI; j++) q.x[j] = slots[64 * j];
+    q.rho = *ph;
+}
+
+// ---- wave A backward: blocks n-1 .. 0 un-applied from C only.  Slot NI b + 1 + g = psi after inner gate g of
+// block b, slot 0 = psi after the surface gates; on exit st.pr / st.pi hold that slot-0 state.
+template <class L, class PL, int LL, int ROT>
+__device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec, int n, const float2* ph, const float2* sp,
+                                                  float* gblk, int lane, int dst_lane) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
+    static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
+    BlkBuf<NI> qa, qb;
+    float d[8];
+    int b = n - 1;
+    float2 held = sp[64 * NI * n];                              // psi after the last inner gate of block n-1
+    const float2 rho_n = ph[64 * n];
+    if (b & 1) load_blk(qb, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
+    else load_blk(qa, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
+    float dzu = 0.f, dzd = 0.f;
+    {
+        const int jt = (n - 1) % UNR;
+        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);   // psi, C after unit n (registers)
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) { dzu = -st.sg[PL::v[2 * I]] * w; dzd = -st.sg[PL::v[2 * I + 1]] * w; }
+        }, typename make_iseq<UNR>::type{});
+        phase_apply<L>(st.cr[0], st.ci[0], rho_n, true);
+    }
+    auto blk = [&](auto jj, BlkBuf<NI>& cur, BlkBuf<NI>& nxt) __attribute__((always_inline)) {
+        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int UP = PL::v[2 * I], DN = PL::v[2 * I + 1];
+        const int bn = b > 0 ? b - 1 : 0;
+        load_blk(nxt, rec + 16 * bn, sp + 64 * NI * bn, ph + 64 * bn);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = 0.f;
+        static_for([&](auto gg) __attribute__((always_inline)) {
+            constexpr int G = NI - 1 - decltype(gg)::value;
+            using IG = InnerGate<ROT, G>;
+            constexpr int Q = IG::template qubit<UP, DN>();
+            float2 ps;
+            if constexpr (G == NI - 1) ps = held; else ps = cur.x[G + 1];
+            st.pr[0] = ps.x; st.pi[0] = ps.y;
+            d[G] = rot_grad<L, IG::KIND, Q>(st);
+            rot_apply<L, IG::KIND, Q>(st.cr, st.ci, cur.r[IG::CS], -cur.r[IG::CS + 1], st);
+        }, typename make_iseq<NI>::type{});
+        phase_apply<L>(st.cr[0], st.ci[0], cur.rho, true);       // C now sits before unit b, where cur.x[0] was stored
+        held = cur.x[0];
+        const float w = fmaf(st.cr[0], held.y, -st.ci[0] * held.x);
+        d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
+        constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
+        d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        dzu = -st.sg[PL::v[2 * IP]] * w;
+        dzd = -st.sg[PL::v[2 * IP + 1]] * w;
+        reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        b--;
+    };
+    const int tail = n % UNR;
+    static_for([&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = UNR - 1 - decltype(jj)::value;
+        if (J < tail) { if constexpr (J & 1) blk(ic<J>{}, qb, qa); else blk(ic<J>{}, qa, qb); }
+    }, typename make_iseq<UNR>::type{});
+    for (int full = n / UNR; full > 0; full--)
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = UNR - 1 - decltype(jj)::value;
+            if constexpr (J & 1) blk(ic<J>{}, qb, qa); else blk(ic<J>{}, qa, qb);
+        }, typename make_iseq<UNR>::type{});
+    st.pr[0] = held.x; st.pi[0] = held.y;
+}
+
+// ---- wave B backward: blocks 0 .. n-1 applied to psi' = conj(f) H1 only.  held = W at the cut on entry;
+// slot NI b + 1 + g = W after inner gate g of (local) block b.
+template <class L, class PL, int LL, int ROT>
+__device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, float2 held, const float* rec, int n, const float2* ph,
+                                                  const float2* sp, float* gblk, int lane, int dst_lane) {
+    constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
+    static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
+    BlkBuf<NI> qa, qb;
+    float da[8], db[8];
+    int b = 0;
+    load_blk(qa, rec, sp + 64, ph);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { da[k] = 0.f; db[k] = 0.f; }
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int UP = PL::v[2 * I], DN = PL::v[2 * I + 1];
+        BlkBuf<NI>& cur = (J & 1) ? qb : qa;
+        BlkBuf<NI>& nxt = (J & 1) ? qa : qb;
+        float (&dcur)[8] = (J & 1) ? db : da;
+        float (&dprv)[8] = (J & 1) ? da : db;
+        const int bn = b + 1 < n ? b + 1 : b;
+        load_blk(nxt, rec + 16 * bn, sp + 64 * (NI * bn + 1), ph + 64 * bn);
+        const float w = fmaf(held.x, st.pi[0], -held.y * st.pr[0]);          // W, psi' before unit b
+        phase_apply<L>(st.pr[0], st.pi[0], cur.rho, false);
+        dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
+        dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
+        if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
+        constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dcur[k] = 0.f;
+        dcur[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        static_for([&](auto gg) __attribute__((always_inline)) {
+            constexpr int G = decltype(gg)::value;
+            using IG = InnerGate<ROT, G>;
+            constexpr int Q = IG::template qubit<UP, DN>();
+            rot_apply<L, IG::KIND, Q>(st.pr, st.pi, cur.r[IG::CS], cur.r[IG::CS + 1], st);
+            st.cr[0] = cur.x[G].x; st.ci[0] = cur.x[G].y;
+            dcur[G] = rot_grad<L, IG::KIND, Q>(st);
+        }, typename make_iseq<NI>::type{});
+        held = cur.x[NI - 1];
+        b++;
+    };
+    for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
+    static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
+    {
+        const int jt = (n - 1) % UNR;
+        const float w = fmaf(held.x, st.pi[0], -held.y * st.pr[0]);          // last unit: the Rz pair of block n-1
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value, I = J % LL;
+            if (J == jt) {
+                float (&dl)[8] = (J & 1) ? db : da;
+                dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
+                dl[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * I + 1]] * w;
+                reduce8_rows(dl, gblk + 32 * (n - 1), lane, dst_lane);
+            }
+        }, typename make_iseq<UNR>::type{});
+    }
+}
+
 __device__ __forceinline__ void split_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int ROT, int PPT, int MSTORE, int... UD>
@@ -322,13 +499,21 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     constexpr int NQ = 3, TH = 128;
     constexpr int LL = sizeof...(UD) / 2;
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
-    constexpr bool STORE = MSTORE != 0;
+    // MSTORE packs two things: bits 0-1 the storage mode (0 rebuild phases, 1 store phases, 2 store phases and
+    // states), bits 2.. the block count K when the kernel is specialised on it (0 = K read from the plan): with K a
+    // constant the sweeps are straight-line code - no prefetch-address clamps, tail guards or loop control
+    // (~400 scalar / branch instructions per sample-step at config 2) and LDS addresses become immediates.
+    constexpr int MS = MSTORE & 3, KC = MSTORE >> 2;
+    constexpr bool STORE = MS != 0;
+    constexpr bool PS = MS == 2;                              // stored-state gradient halves
+    constexpr int NI = 2 * (NR - 1);
     static_assert(layered_merge(3, 0, ROT), "two-ended kernel: rotation string must end in 'z'");
     static_assert(L::E == 1, "two-ended kernel: one element per lane");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.P, K = (P - NS) / NB;
+    const int P = KC > 0 ? NS + NB * KC : a.P, K = KC > 0 ? KC : (P - NS) / NB;
+    if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
     const int m = split_point(K, LL), kb = K - m;
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
@@ -338,6 +523,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     float* red = smem + Lds::red(K);
     float2* xch = reinterpret_cast<float2*>(smem + Lds::xch(K)) + lane;                 // [0]: psi of wave A, [64]: W of wave B
     float2* ph = reinterpret_cast<float2*>(smem + Lds::phase(K)) + lane + (wave ? 64 * (m + 1) : 0);
+    float2* sp = reinterpret_cast<float2*>(smem + Lds::states(K)) + lane + (wave ? 64 * (NI * m + 1) : 0);
 
     State<L> st;
 #pragma unroll
@@ -420,11 +606,12 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
                 rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
                 rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
             }, typename make_iseq<NQ>::type{});
-            split_fwd<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph);
+            if constexpr (PS) sp[0] = make_float2(st.pr[0], st.pi[0]);
+            split_fwd<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS, m, ph, sp);
             xch[0] = make_float2(st.pr[0], st.pi[0]);
         } else {
             st.pr[0] = vt.x; st.pi[0] = vt.y;
-            split_inv<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph);
+            split_inv<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
             xch[64] = make_float2(st.pr[0], st.pi[0]);
         }
         CPF_STAMP(0)                                  // forward half done
@@ -463,11 +650,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         // ================= backward: C = f W at the cut
         {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
-            st.cr[0] = fmaf(fr, wr, -fi * wi);
-            st.ci[0] = fmaf(fr, wi, fi * wr);
+            if (!PS || wave == 0) {
+                st.cr[0] = fmaf(fr, wr, -fi * wi);
+                st.ci[0] = fmaf(fr, wi, fi * wr);
+            } else {                                  // wave B, stored states: f moves onto psi
+                const float qr = fmaf(fr, st.pr[0], fi * st.pi[0]), qi = fmaf(fr, st.pi[0], -fi * st.pr[0]);
+                st.pr[0] = qr; st.pi[0] = qi;
+            }
         }
         if (wave == 0) {
-            split_bwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph, gs + 32 * Lds::NBATCH, lane, dst_lane);
+            if constexpr (PS) split_bwd_grad_ps<L, PL, LL, ROT>(st, smem + Lds::BLK_CS, m, ph, sp, gs + 32 * Lds::NBATCH, lane, dst_lane);
+            else split_bwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph, gs + 32 * Lds::NBATCH, lane, dst_lane);
             float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
 #pragma unroll
             for (int i = 0; i < Lds::SURF_F / 4; i++) {
@@ -485,8 +678,12 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
                 reduce8_rows(d8, gs + 32 * bt, lane, dst_lane);
             }
         } else {
-            split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
-                                                  lane, dst_lane);
+            if constexpr (PS)
+                split_fwd_grad_ps<L, PL, LL, ROT>(st, make_float2(wr, wi), smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
+                                                  gs + 32 * Lds::NBATCH + 32 * m, lane, dst_lane);
+            else
+                split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
+                                                      lane, dst_lane);
         }
         CPF_STAMP(3)                                  // backward half done
         split_barrier();

@@ -145,16 +145,46 @@ bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int ro
     { const char* e = getenv("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
     return S <= (int64_t)plan->num_cu * 4;
 }
+// Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
+// them while LDS still admits the workgroups the launch wants on a CU.
+bool states_fit(int num_cu, int64_t S, int rot_code, size_t lds_bytes_with_states) {
+    if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > 64 * 1024) return false;
+    { const char* e = getenv("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    const int64_t want = std::min<int64_t>((S + num_cu - 1) / num_cu, 4);
+    return (int64_t)(160 * 1024 / lds_bytes_with_states) >= want;
+}
+// K-specialised two-ended kernels exist ahead of time for the BASELINE 3-qubit configurations
+// (chain_layer(3) with 12 blocks, connected_layer(3) with 16; 'xyz'); KC = 0: K is read from the plan.
+template <int ROT, int PPT, int KC, int... UD>
+int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+    const size_t lds2 = (size_t)cpf::SplitLds::total(K, 2, cpf::inner_gates<ROT>()) * sizeof(float);
+    const char* tag = KC ? " K" : "";
+    if constexpr (cpf::rot_nr(ROT) >= 2) {
+        if (states_fit(plan->num_cu, S, ROT, lds2)) {
+            hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT, 2 + 4 * KC, UD...>), dim3((unsigned)S), dim3(128), lds2, stream, a);
+            CPF_HIP(hipGetLastError());
+            plan->variant = std::string("split/aot waves=2 states") + tag;
+            return 0;
+        }
+    }
+    const size_t lds = (size_t)cpf::SplitLds::total(K, 1) * sizeof(float);
+    hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT, 1 + 4 * KC, UD...>), dim3((unsigned)S), dim3(128), lds, stream, a);
+    CPF_HIP(hipGetLastError());
+    plan->variant = std::string("split/aot waves=2") + tag;
+    return 0;
+}
 template <int ROT, int PPT, int... UD>
 int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
     cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
     plan->variant = "layered/aot waves=1";
     if (want_split(plan, a, K, (int)sizeof...(UD) / 2, ROT, S)) {
-        const size_t lds = (size_t)cpf::SplitLds::total(K, true) * sizeof(float);
-        hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT / 2, 1, UD...>), dim3((unsigned)S), dim3(128), lds, stream, a);
-        CPF_HIP(hipGetLastError());
-        plan->variant = "split/aot waves=2";
-        return 0;
+        constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
+        constexpr int LL = (int)sizeof...(UD) / 2;
+        const char* e = getenv("CPF_KSPEC");                                       // A/B and tests: 0 = K from the plan
+        const bool kspec = !(e && e[0] == '0');
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 2) { if (kspec && K == 12) return launch_split3<ROT, PPT / 2, 12, UD...>(plan, a, K, S, stream); }
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 3) { if (kspec && K == 16) return launch_split3<ROT, PPT / 2, 16, UD...>(plan, a, K, S, stream); }
+        return launch_split3<ROT, PPT / 2, 0, UD...>(plan, a, K, S, stream);
     }
     const bool merge = cpf::layered_merge(3, 0, ROT);
     const size_t lds1 = (size_t)cpf::LayeredLds<3>::total(K, 1, merge) * sizeof(float);
@@ -232,15 +262,18 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     int mstore = 0;
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S)) {
         const int sppt = (a.P + 127) / 128;
-        const size_t slds = (size_t)cpf::SplitLds::total(plan->K, true) * sizeof(float);
+        const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
+        const char* jk = getenv("CPF_JIT_K");                                    // opt-in: one build per block count
+        const int smstore = (states_fit(plan->num_cu, S, rot_code, slds2) ? 2 : 1) + ((jk && jk[0] == '1') ? 4 * plan->K : 0);
+        const size_t slds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
         std::string serr;
-        hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, 1, plan->layer_ud, &serr, true) : nullptr;
+        hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, smstore, plan->layer_ud, &serr, true) : nullptr;
         if (sfn) {
             cpf::KArgs args = a;
             void* params[] = {&args};
             const hipError_t e = hipModuleLaunchKernel(sfn, (unsigned)S, 1, 1, 128, 1, 1, (unsigned)slds, stream, params, nullptr);
             *rc = e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
-            plan->variant = "split/jit waves=2";
+            plan->variant = std::string((smstore & 3) == 2 ? "split/jit waves=2 states" : "split/jit waves=2") + (smstore >> 2 ? " K" : "");
             return true;
         }
         plan->jit_note = serr;          // fall through to the one-wave kernel

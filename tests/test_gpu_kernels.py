@@ -286,19 +286,29 @@ def test_merged_diagonal_runs_both_variants(layer, K, rot, mstore, monkeypatch):
                                          ([[0, 1], [1, 2]], 7, 'xz'), ([[2, 0], [1, 2], [0, 1]], 7, 'xyz'),
                                          ([[0, 1], [1, 2]], 4, 'z'), ([[1, 0], [2, 0]], 5, 'yz'),
                                          ([[1, 2], [0, 1]], 5, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 64, 'xz')])
-def test_two_ended_kernel_matches_oracle(layer, K, rot, monkeypatch):
+@pytest.mark.parametrize('pstore,kspec', [('0', '0'), ('1', '1'), ('1', '0'), ('0', '1')])
+def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypatch):
     """Two waves per sample (cpf_split.h): wave A builds the first half of the circuit from the identity, wave B
     un-applies the second half from the target, gradients come from a backward sweep (A) and a forward sweep (B).
     Against the float64 oracle over a short run with history, a frozen mask and the penalty on; ahead-of-time and
-    runtime-built instances, whole and truncated layers, K up to the 64-block limit."""
+    runtime-built instances, whole and truncated layers, K up to the 64-block limit; gradient halves that un-apply
+    psi and C (pstore 0) or read stored states back (pstore 1), K from the plan or as a compile-time constant."""
     target = _rand_unitary(3, 22)
     T, S = 14, 5
     monkeypatch.setenv('CPF_SPLIT', '1')
+    monkeypatch.setenv('CPF_PSTORE', pstore)
+    monkeypatch.setenv('CPF_KSPEC', kspec)
+    monkeypatch.setenv('CPF_JIT_K', kspec)
     orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     init = orc.initial_angles(9, S)
     out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
     assert eng.last_variant().startswith('split/'), eng.last_variant()
+    if rot == 'xyz' and K in (12, 16):                # the BASELINE shapes: every ahead-of-time variant is reachable
+        want = 'split/aot waves=2' + (' states' if pstore == '1' else '') + (' K' if kspec == '1' else '')
+        assert eng.last_variant() == want, eng.last_variant()
+    if len(rot) >= 2 and K <= 16:
+        assert ('states' in eng.last_variant()) == (pstore == '1'), eng.last_variant()
     ref = orc.run(init, np.float64, keep_history=True)
     tol = 1e-5 if K <= 16 else 3e-5
     assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < tol / 2
