@@ -168,56 +168,76 @@ __device__ __forceinline__ void wave_sum2(float& x, float& y) {
     y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));
 }
 
+// ------------------------------------------------------------------ packed complex arithmetic
+// A complex amplitude lives in an even-aligned register pair (re, im).  v_pk_mul_f32 / v_pk_fma_f32 take one
+// issue slot like their scalar forms (measured: tools/micro/valu_rate.hip, 4 cycles per wave64 instruction per
+// SIMD either way) and can swap, broadcast and negate the halves of an operand for free (op_sel / neg_lo /
+// neg_hi), so a complex multiply is 2 instructions instead of 4 and a rotation whose partner amplitude arrives
+// over DPP is 2 x v_mul_f32_dpp + 1 x v_pk_fma_f32 instead of 4 (tools/micro/pk_gate.hip: -21 % at saturation).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 swp(f2 v) { return f2{v.y, v.x}; }
+// x * (rho.x + i rho.y)  /  x * conj(rho).  hipcc folds a per-half sign into neg_lo / neg_hi only when the negated
+// factor is a scalar of its own (as in the Rz forms below), not an element of a register pair; for a pair-valued
+// rho the signed broadcast (-rho.y, rho.y) costs one v_pk_mul_f32 by a constant pair, shared when the same rho
+// multiplies psi and C: 3 (or 2.5) instructions instead of 4 (tools/micro: /tmp experiments in DESIGN.md).
+__device__ __forceinline__ f2 cmul(f2 x, f2 rho) { return pk_fma(splat(rho.y) * f2{-1.f, 1.f}, swp(x), splat(rho.x) * x); }
+__device__ __forceinline__ f2 cmul_conj(f2 x, f2 rho) { return pk_fma(splat(rho.y) * f2{1.f, -1.f}, swp(x), splat(rho.x) * x); }
+// (re, im) -> (i * s) * (re, im) = (-s im, s re);  (-i s) * (re, im) = (s im, -s re)
+__device__ __forceinline__ f2 mul_pi(f2 x, float s) { return f2{-s, s} * swp(x); }
+__device__ __forceinline__ f2 mul_mi(f2 x, float s) { return f2{s, -s} * swp(x); }
+
 // ------------------------------------------------------------------ per-thread state
 template <class L>
 struct State {
-    float pr[L::E], pi[L::E];      // psi  (the unitary being built / un-built)
-    float cr[L::E], ci[L::E];      // C    (cotangent of the loss, scaled by 1/2)
+    f2 p[L::E];                    // psi  (the unitary being built / un-built), (re, im)
+    f2 c[L::E];                    // C    (cotangent of the loss, scaled by 1/2)
     float sg[L::NLR > 0 ? L::NLR : 1];   // +1 if this lane's bit of lane-row-qubit i is set, else -1
+    f2 sgp[L::NLR > 0 ? L::NLR : 1];     // (1, sg): turns a record's (cos, sin) into cos + i sigma sin in one packed multiply
     bool lb[L::NLR > 0 ? L::NLR : 1];
 };
 
-// ---- rotations: forward / inverse application to one matrix (re, im)
+// ---- rotations: forward / inverse application to one matrix
 // s is sin(a/2) for the forward gate, -sin(a/2) for the inverse.
 template <class L, int KIND, int Q>
-__device__ __forceinline__ void rot_apply(float (&re)[L::E], float (&im)[L::E], float c, float s, const State<L>& st) {
+__device__ __forceinline__ void rot_apply(f2 (&x)[L::E], float c, float s, const State<L>& st) {
     constexpr int BIT = L::row_bit(Q);
     if constexpr (L::row_on_lane(Q)) {
         const float ss = st.sg[Q] * s;
 #pragma unroll
         for (int e = 0; e < L::E; e++) {
-            float nr, ni;
-            // the partner amplitude enters through a plain multiply so that the DPP read folds into it
-            // (v_mul_f32_dpp); hipcc does not fold DPP reads into v_fma / v_fmac operands
+            // the partner amplitude enters through plain multiplies so that the DPP reads fold into them
+            // (v_mul_f32_dpp); the c * x + t part is one v_pk_fma_f32
             if constexpr (KIND == OP_RX) {
-                const float tr_ = s * xor_lane<BIT>(im[e]), ti_ = s * xor_lane<BIT>(re[e]);
-                nr = fmaf(c, re[e], tr_);
-                ni = fmaf(c, im[e], -ti_);
+                f2 t;
+                t.x = s * xor_lane<BIT>(x[e].y);
+                t.y = -s * xor_lane<BIT>(x[e].x);
+                x[e] = pk_fma(splat(c), x[e], t);
             } else if constexpr (KIND == OP_RY) {
-                const float tr_ = ss * xor_lane<BIT>(re[e]), ti_ = ss * xor_lane<BIT>(im[e]);
-                nr = fmaf(c, re[e], tr_);
-                ni = fmaf(c, im[e], ti_);
+                f2 t;
+                t.x = ss * xor_lane<BIT>(x[e].x);
+                t.y = ss * xor_lane<BIT>(x[e].y);
+                x[e] = pk_fma(splat(c), x[e], t);
             } else {
-                nr = fmaf(-ss, im[e], c * re[e]);
-                ni = fmaf(ss, re[e], c * im[e]);
+                x[e] = pk_fma(f2{-ss, ss}, swp(x[e]), splat(c) * x[e]);
             }
-            re[e] = nr; im[e] = ni;
         }
     } else {
 #pragma unroll
         for (int e0 = 0; e0 < L::E; e0++) {
             if (e0 & (1 << BIT)) continue;
             const int e1 = e0 | (1 << BIT);
-            float r0 = re[e0], i0 = im[e0], r1 = re[e1], i1 = im[e1];
-            if constexpr (KIND == OP_RX) {
-                re[e0] = fmaf(s, i1, c * r0);  im[e0] = fmaf(-s, r1, c * i0);
-                re[e1] = fmaf(s, i0, c * r1);  im[e1] = fmaf(-s, r0, c * i1);
-            } else if constexpr (KIND == OP_RY) {
-                re[e0] = fmaf(-s, r1, c * r0); im[e0] = fmaf(-s, i1, c * i0);
-                re[e1] = fmaf(s, r0, c * r1);  im[e1] = fmaf(s, i0, c * i1);
-            } else {
-                re[e0] = fmaf(s, i0, c * r0);  im[e0] = fmaf(-s, r0, c * i0);
-                re[e1] = fmaf(-s, i1, c * r1); im[e1] = fmaf(s, r1, c * i1);
+            const f2 a = x[e0], b = x[e1];
+            if constexpr (KIND == OP_RX) {            // a' = c a - i s b, b' = c b - i s a
+                x[e0] = pk_fma(f2{s, -s}, swp(b), splat(c) * a);
+                x[e1] = pk_fma(f2{s, -s}, swp(a), splat(c) * b);
+            } else if constexpr (KIND == OP_RY) {     // a' = c a - s b, b' = c b + s a
+                x[e0] = pk_fma(splat(-s), b, splat(c) * a);
+                x[e1] = pk_fma(splat(s), a, splat(c) * b);
+            } else {                                  // a' = (c - i s) a, b' = (c + i s) b
+                x[e0] = pk_fma(f2{s, -s}, swp(a), splat(c) * a);
+                x[e1] = pk_fma(f2{-s, s}, swp(b), splat(c) * b);
             }
         }
     }
@@ -228,40 +248,58 @@ __device__ __forceinline__ void rot_apply(float (&re)[L::E], float (&im)[L::E], 
 template <class L, int KIND, int Q>
 __device__ __forceinline__ float rot_grad(const State<L>& st) {
     constexpr int BIT = L::row_bit(Q);
-    float u = 0.f;
     if constexpr (L::row_on_lane(Q)) {
-#pragma unroll
-        for (int e = 0; e < L::E; e++) {
+        if constexpr (L::E == 1) {
             if constexpr (KIND == OP_RX) {
-                const float t1 = st.cr[e] * xor_lane<BIT>(st.pi[e]), t2 = st.ci[e] * xor_lane<BIT>(st.pr[e]);
-                u += t1 - t2;
+                const float t1 = st.c[0].x * xor_lane<BIT>(st.p[0].y), t2 = st.c[0].y * xor_lane<BIT>(st.p[0].x);
+                return t1 - t2;
             } else if constexpr (KIND == OP_RY) {
-                const float t1 = st.cr[e] * xor_lane<BIT>(st.pr[e]), t2 = st.ci[e] * xor_lane<BIT>(st.pi[e]);
-                u += t1 + t2;
+                const float t1 = st.c[0].x * xor_lane<BIT>(st.p[0].x), t2 = st.c[0].y * xor_lane<BIT>(st.p[0].y);
+                return st.sg[Q] * (t1 + t2);
             } else {
-                u = fmaf(st.cr[e], st.pi[e], u); u = fmaf(-st.ci[e], st.pr[e], u);
+                return -st.sg[Q] * fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);
             }
+        } else {
+            f2 acc = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < L::E; e++) {
+                if constexpr (KIND == OP_RX) {        // (Cr X(psi_i), Ci X(psi_r))
+                    f2 t;
+                    t.x = st.c[e].x * xor_lane<BIT>(st.p[e].y);
+                    t.y = st.c[e].y * xor_lane<BIT>(st.p[e].x);
+                    acc += t;
+                } else if constexpr (KIND == OP_RY) { // (Cr X(psi_r), Ci X(psi_i))
+                    f2 t;
+                    t.x = st.c[e].x * xor_lane<BIT>(st.p[e].x);
+                    t.y = st.c[e].y * xor_lane<BIT>(st.p[e].y);
+                    acc += t;
+                } else {                              // (Cr psi_i, Ci psi_r)
+                    acc = pk_fma(st.c[e], swp(st.p[e]), acc);
+                }
+            }
+            if constexpr (KIND == OP_RX) return acc.x - acc.y;
+            else if constexpr (KIND == OP_RY) return st.sg[Q] * (acc.x + acc.y);
+            else return -st.sg[Q] * (acc.x - acc.y);
         }
-        if constexpr (KIND == OP_RX) return u;
-        else if constexpr (KIND == OP_RY) return st.sg[Q] * u;
-        else return -st.sg[Q] * u;
     } else {
+        f2 acc = {0.f, 0.f};
 #pragma unroll
         for (int e0 = 0; e0 < L::E; e0++) {
             if (e0 & (1 << BIT)) continue;
             const int e1 = e0 | (1 << BIT);
-            if constexpr (KIND == OP_RX) {
-                u = fmaf(st.cr[e0], st.pi[e1], u); u = fmaf(-st.ci[e0], st.pr[e1], u);
-                u = fmaf(st.cr[e1], st.pi[e0], u); u = fmaf(-st.ci[e1], st.pr[e0], u);
-            } else if constexpr (KIND == OP_RY) {
-                u = fmaf(-st.cr[e0], st.pr[e1], u); u = fmaf(-st.ci[e0], st.pi[e1], u);
-                u = fmaf(st.cr[e1], st.pr[e0], u);  u = fmaf(st.ci[e1], st.pi[e0], u);
-            } else {
-                u = fmaf(st.cr[e0], st.pi[e0], u);  u = fmaf(-st.ci[e0], st.pr[e0], u);
-                u = fmaf(-st.cr[e1], st.pi[e1], u); u = fmaf(st.ci[e1], st.pr[e1], u);
+            if constexpr (KIND == OP_RX) {            // Cr0 pi1 - Ci0 pr1 + Cr1 pi0 - Ci1 pr0
+                acc = pk_fma(st.c[e0], swp(st.p[e1]), acc);
+                acc = pk_fma(st.c[e1], swp(st.p[e0]), acc);
+            } else if constexpr (KIND == OP_RY) {     // -Cr0 pr1 - Ci0 pi1 + Cr1 pr0 + Ci1 pi0
+                acc = pk_fma(st.c[e1], st.p[e0], acc);
+                acc = pk_fma(-st.c[e0], st.p[e1], acc);
+            } else {                                  // Cr0 pi0 - Ci0 pr0 - Cr1 pi1 + Ci1 pr1
+                acc = pk_fma(st.c[e0], swp(st.p[e0]), acc);
+                acc = pk_fma(-st.c[e1], swp(st.p[e1]), acc);
             }
         }
-        return u;
+        if constexpr (KIND == OP_RY) return acc.x + acc.y;
+        else return acc.x - acc.y;
     }
 }
 
@@ -281,41 +319,39 @@ __host__ __device__ constexpr bool cp_reg_sel(int e) {
     return s;
 }
 template <class L, int Q0, int Q1>
-__device__ __forceinline__ void cp_apply(float (&re)[L::E], float (&im)[L::E], float cc, float sc, const State<L>& st) {
+__device__ __forceinline__ void cp_apply(f2 (&x)[L::E], float cc, float sc, const State<L>& st) {
     const bool p = cp_lane_pred<L, Q0, Q1>(st);
-    const float ce = p ? cc : 1.f, se = p ? sc : 0.f;
+    const f2 rho = {p ? cc : 1.f, p ? sc : 0.f};
 #pragma unroll
     for (int e = 0; e < L::E; e++) {
         if (!cp_reg_sel<L, Q0, Q1>(e)) continue;
-        float nr = fmaf(-se, im[e], ce * re[e]);
-        float ni = fmaf(se, re[e], ce * im[e]);
-        re[e] = nr; im[e] = ni;
+        x[e] = cmul(x[e], rho);
     }
 }
 // d/da: dU = i |11><11| U  ->  dL/da = -2 sum_{11} (Cr psi_i - Ci psi_r)   (C carries 1/2)
 template <class L, int Q0, int Q1>
 __device__ __forceinline__ float cp_grad(const State<L>& st) {
-    float u = 0.f;
+    f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < L::E; e++) {
         if (!cp_reg_sel<L, Q0, Q1>(e)) continue;
-        u = fmaf(st.cr[e], st.pi[e], u); u = fmaf(-st.ci[e], st.pr[e], u);
+        acc = pk_fma(st.c[e], swp(st.p[e]), acc);
     }
-    return cp_lane_pred<L, Q0, Q1>(st) ? -2.f * u : 0.f;
+    return cp_lane_pred<L, Q0, Q1>(st) ? -2.f * (acc.x - acc.y) : 0.f;
 }
 
 // ---- CNOT (gates.py:40-43 cx_mat): control QC ("up"), target QT ("down"); a row permutation, its own inverse
 template <class L, int QC, int QT>
-__device__ __forceinline__ void cx_apply(float (&re)[L::E], float (&im)[L::E], const State<L>& st) {
+__device__ __forceinline__ void cx_apply(f2 (&x)[L::E], const State<L>& st) {
     constexpr int BC = L::row_bit(QC), BT = L::row_bit(QT);
     if constexpr (L::row_on_lane(QT)) {
 #pragma unroll
         for (int e = 0; e < L::E; e++) {
             bool ctl;
             if constexpr (L::row_on_lane(QC)) ctl = st.lb[QC]; else ctl = (e >> BC) & 1;
-            const float qr = xor_lane<BT>(re[e]), qi = xor_lane<BT>(im[e]);
-            re[e] = ctl ? qr : re[e];
-            im[e] = ctl ? qi : im[e];
+            const float qr = xor_lane<BT>(x[e].x), qi = xor_lane<BT>(x[e].y);
+            x[e].x = ctl ? qr : x[e].x;
+            x[e].y = ctl ? qi : x[e].y;
         }
     } else {
 #pragma unroll
@@ -324,9 +360,9 @@ __device__ __forceinline__ void cx_apply(float (&re)[L::E], float (&im)[L::E], c
             const int e1 = e0 | (1 << BT);
             bool ctl;
             if constexpr (L::row_on_lane(QC)) ctl = st.lb[QC]; else ctl = (e0 >> BC) & 1;
-            const float r0 = re[e0], i0 = im[e0], r1 = re[e1], i1 = im[e1];
-            re[e0] = ctl ? r1 : r0; im[e0] = ctl ? i1 : i0;
-            re[e1] = ctl ? r0 : r1; im[e1] = ctl ? i0 : i1;
+            const f2 a = x[e0], b = x[e1];
+            x[e0].x = ctl ? b.x : a.x; x[e0].y = ctl ? b.y : a.y;
+            x[e1].x = ctl ? a.x : b.x; x[e1].y = ctl ? a.y : b.y;
         }
     }
 }
@@ -359,17 +395,17 @@ __device__ __forceinline__ void cx_apply(float (&re)[L::E], float (&im)[L::E], c
 template <class L>
 __device__ __forceinline__ void op_forward(int kind, int q0, int q1, float c, float s, State<L>& st) {
     switch (kind) {
-        case OP_RX: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RX, Q>(st.pr, st.pi, c, s, st))); break;
-        case OP_RY: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RY, Q>(st.pr, st.pi, c, s, st))); break;
-        case OP_RZ: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RZ, Q>(st.pr, st.pi, c, s, st))); break;
+        case OP_RX: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RX, Q>(st.p, c, s, st))); break;
+        case OP_RY: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RY, Q>(st.p, c, s, st))); break;
+        case OP_RZ: CPF_Q_SWITCH(q0, (rot_apply<L, OP_RZ, Q>(st.p, c, s, st))); break;
         case OP_CX: {
-#define BODY_PAIR cx_apply<L, Q0, Q1>(st.pr, st.pi, st)
+#define BODY_PAIR cx_apply<L, Q0, Q1>(st.p, st)
             switch (q0 * 8 + q1) { CPF_ALL_ORDERED_PAIRS default: break; }
 #undef BODY_PAIR
         } break;
         default: {
             if (kind == OP_CZ) { c = -1.f; s = 0.f; }
-#define BODY_PAIR cp_apply<L, Q0, Q1>(st.pr, st.pi, c, s, st)
+#define BODY_PAIR cp_apply<L, Q0, Q1>(st.p, c, s, st)
             switch (q0 * 8 + q1) {
                 CPF_PAIR_CASE(0, 1) CPF_PAIR_CASE(0, 2) CPF_PAIR_CASE(1, 2)
                 CPF_PAIR_CASE(0, 3) CPF_PAIR_CASE(1, 3) CPF_PAIR_CASE(2, 3)
@@ -389,14 +425,14 @@ __device__ __forceinline__ float op_backward(int kind, int q0, int q1, float c, 
     switch (kind) {
 #define CPF_ROT_BWD(KIND)                                                         \
         CPF_Q_SWITCH(q0, (d = rot_grad<L, KIND, Q>(st),                           \
-                          rot_apply<L, KIND, Q>(st.pr, st.pi, c, -s, st),         \
-                          rot_apply<L, KIND, Q>(st.cr, st.ci, c, -s, st)))
+                          rot_apply<L, KIND, Q>(st.p, c, -s, st),         \
+                          rot_apply<L, KIND, Q>(st.c, c, -s, st)))
         case OP_RX: CPF_ROT_BWD(OP_RX); break;
         case OP_RY: CPF_ROT_BWD(OP_RY); break;
         case OP_RZ: CPF_ROT_BWD(OP_RZ); break;
 #undef CPF_ROT_BWD
         case OP_CX: {
-#define BODY_PAIR (cx_apply<L, Q0, Q1>(st.pr, st.pi, st), cx_apply<L, Q0, Q1>(st.cr, st.ci, st))
+#define BODY_PAIR (cx_apply<L, Q0, Q1>(st.p, st), cx_apply<L, Q0, Q1>(st.c, st))
             switch (q0 * 8 + q1) { CPF_ALL_ORDERED_PAIRS default: break; }
 #undef BODY_PAIR
         } break;
@@ -404,8 +440,8 @@ __device__ __forceinline__ float op_backward(int kind, int q0, int q1, float c, 
             const bool is_cz = (kind == OP_CZ);
             if (is_cz) { c = -1.f; s = 0.f; }
 #define BODY_PAIR (d = is_cz ? 0.f : cp_grad<L, Q0, Q1>(st),                      \
-                   cp_apply<L, Q0, Q1>(st.pr, st.pi, c, -s, st),                  \
-                   cp_apply<L, Q0, Q1>(st.cr, st.ci, c, -s, st))
+                   cp_apply<L, Q0, Q1>(st.p, c, -s, st),                  \
+                   cp_apply<L, Q0, Q1>(st.c, c, -s, st))
             switch (q0 * 8 + q1) {
                 CPF_PAIR_CASE(0, 1) CPF_PAIR_CASE(0, 2) CPF_PAIR_CASE(1, 2)
                 CPF_PAIR_CASE(0, 3) CPF_PAIR_CASE(1, 3) CPF_PAIR_CASE(2, 3)
@@ -552,15 +588,16 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
     for (int i = 0; i < L::NLR; i++) {
         st.lb[i] = (lane >> L::row_lane_bit(i)) & 1;
         st.sg[i] = st.lb[i] ? 1.f : -1.f;
+        st.sgp[i] = f2{1.f, st.sg[i]};
     }
     const int col = L::col_index(lane, wave);
-    float vr[E], vi[E];
+    f2 vt[E];
     bool diag[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int row = L::row_index(lane, e);
         const float2 t = a.target[row * L::D + col];
-        vr[e] = t.x; vi[e] = t.y;
+        vt[e] = f2{t.x, t.y};
         diag[e] = (row == col);
     }
 
@@ -596,7 +633,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         const float2 bc = const_load_f2(a.bias, (a.mode == MODE_OPTIMIZE && a.T > 0) ? it : 0);
         // ---- forward: psi = G_{G-1} ... G_0
 #pragma unroll
-        for (int e = 0; e < E; e++) { st.pr[e] = diag[e] ? 1.f : 0.f; st.pi[e] = 0.f; }
+        for (int e = 0; e < E; e++) st.p[e] = f2{diag[e] ? 1.f : 0.f, 0.f};
         {
             float4 rc = rec[0];
             for (int g = 0; g < G; g++) {
@@ -612,7 +649,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
             for (int e = 0; e < E; e++) {
                 const int row = L::row_index(lane, e);
                 if (((row | col) & msk) == 0)
-                    a.out_U[(s_idx * N + (row >> d)) * N + (col >> d)] = make_float2(st.pr[e], st.pi[e]);
+                    a.out_U[(s_idx * N + (row >> d)) * N + (col >> d)] = make_float2(st.p[e].x, st.p[e].y);
             }
             return;
         }
@@ -621,13 +658,15 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         if (a.loss_kind == 2) {
 #pragma unroll
             for (int e = 0; e < E; e++)                       // sum |V|^2 |psi|^2
-                acc[0] = fmaf(fmaf(vr[e], vr[e], vi[e] * vi[e]), fmaf(st.pr[e], st.pr[e], st.pi[e] * st.pi[e]), acc[0]);
+                acc[0] = fmaf(fmaf(vt[e].x, vt[e].x, vt[e].y * vt[e].y), fmaf(st.p[e].x, st.p[e].x, st.p[e].y * st.p[e].y), acc[0]);
         } else {
+            f2 tt = {0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < E; e++) {                     // T = sum psi conj(V)
-                acc[0] = fmaf(st.pr[e], vr[e], acc[0]); acc[0] = fmaf(st.pi[e], vi[e], acc[0]);
-                acc[1] = fmaf(st.pi[e], vr[e], acc[1]); acc[1] = fmaf(-st.pr[e], vi[e], acc[1]);
+                tt = pk_fma(splat(vt[e].x), st.p[e], tt);
+                tt = pk_fma(f2{vt[e].y, -vt[e].y}, swp(st.p[e]), tt);
             }
+            acc[0] = tt.x; acc[1] = tt.y;
         }
         if (a.use_reg) {
             for (int j = tid; j < P; j += L::THREADS) {
@@ -668,16 +707,14 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
         if (a.loss_kind == 2) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const float w = -a.inv_dim2 * fmaf(vr[e], vr[e], vi[e] * vi[e]);
-                st.cr[e] = w * st.pr[e];
-                st.ci[e] = w * st.pi[e];
+                const float w = -a.inv_dim2 * fmaf(vt[e].x, vt[e].x, vt[e].y * vt[e].y);
+                st.c[e] = splat(w) * st.p[e];
             }
         } else {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                st.cr[e] = fmaf(fr, vr[e], -fi * vi[e]);
-                st.ci[e] = fmaf(fr, vi[e], fi * vr[e]);
+                st.c[e] = cmul(vt[e], f2{fr, fi});
             }
         }
         {

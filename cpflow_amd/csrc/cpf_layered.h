@@ -75,20 +75,15 @@ __host__ __device__ constexpr bool layered_merge(int nq, int lw, int rot) {
     return nq == 3 && lw == 0 && rot_nr(rot) >= 1 && rot_kind(rot, rot_nr(rot) - 1) == OP_RZ;
 }
 template <class L, int PUP, int PDN, int UP, int DN>
-__device__ __forceinline__ float2 diag_phase(const State<L>& st, float cu, float su, float cd, float sd, float cc, float sc) {
+__device__ __forceinline__ f2 diag_phase(const State<L>& st, float cu, float su, float cd, float sd, float cc, float sc) {
     constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
-    const float ssu = st.sg[PUP] * su, ssd = st.sg[PDN] * sd;          // Rz(a) multiplies by cos(a/2) + i sigma sin(a/2)
-    const float t1 = fmaf(-ssu, ssd, cu * cd), t2 = fmaf(cu, ssd, ssu * cd);
-    const bool p = cp_lane_pred<L, Q0, Q1>(st);                        // CP multiplies the |11> rows by e^{ia}
-    const float ce = p ? cc : 1.f, se = p ? sc : 0.f;
-    return make_float2(fmaf(-t2, se, t1 * ce), fmaf(t2, ce, t1 * se));
+    const f2 zu = f2{cu, su} * st.sgp[PUP], zd = f2{cd, sd} * st.sgp[PDN];   // Rz(a) multiplies by cos(a/2) + i sigma sin(a/2)
+    const bool p = cp_lane_pred<L, Q0, Q1>(st);                              // CP multiplies the |11> rows by e^{ia}
+    const f2 ze = {p ? cc : 1.f, p ? sc : 0.f};
+    return cmul(cmul(zu, zd), ze);
 }
 template <class L>
-__device__ __forceinline__ void phase_apply(float& re, float& im, float2 rho, bool conj) {
-    const float qi = conj ? -rho.y : rho.y;
-    const float nr = fmaf(-qi, im, rho.x * re), ni = fmaf(qi, re, rho.x * im);
-    re = nr; im = ni;
-}
+__device__ __forceinline__ void phase_apply(f2& x, f2 rho, bool conj) { x = conj ? cmul_conj(x, rho) : cmul(x, rho); }
 // the rotations of a block except the final letter's pair (used with merged diagonal runs)
 template <class L, int UP, int DN, int ROT>
 __device__ __forceinline__ void lay_block_fwd_inner(State<L>& st, const float (&r)[16]) {
@@ -96,11 +91,11 @@ __device__ __forceinline__ void lay_block_fwd_inner(State<L>& st, const float (&
 #pragma unroll
     for (int i = 0; i < NR - 1; i++) {
         if (rot_kind(ROT, i) == OP_RX) {
-            rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+            rot_apply<L, OP_RX, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RX, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         } else if (rot_kind(ROT, i) == OP_RY) {
-            rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+            rot_apply<L, OP_RY, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RY, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         } else {
-            rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st);
+            rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         }
     }
 }
@@ -132,19 +127,19 @@ template <class L, int UP, int DN, int ROT>
 __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]) {
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
     constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
-    cp_apply<L, Q0, Q1>(st.pr, st.pi, r[2 * (NB - 1)], r[2 * (NB - 1) + 1], st);
+    cp_apply<L, Q0, Q1>(st.p, r[2 * (NB - 1)], r[2 * (NB - 1) + 1], st);
     gate_fence<L>();
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         if (rot_kind(ROT, i) == OP_RX) {
-            rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
-            rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+            rot_apply<L, OP_RX, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RX, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
         } else if (rot_kind(ROT, i) == OP_RY) {
-            rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
-            rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+            rot_apply<L, OP_RY, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RY, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
         } else {
-            rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
-            rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+            rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
         }
     }
 }
@@ -152,9 +147,9 @@ template <class L, int KIND, int Q>
 __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s) {
     const float d = rot_grad<L, KIND, Q>(st);
     gate_fence<L>();
-    rot_apply<L, KIND, Q>(st.pr, st.pi, c, -s, st);
+    rot_apply<L, KIND, Q>(st.p, c, -s, st);
     gate_fence<L>();
-    rot_apply<L, KIND, Q>(st.cr, st.ci, c, -s, st);
+    rot_apply<L, KIND, Q>(st.c, c, -s, st);
     gate_fence<L>();
     return d;
 }
@@ -176,8 +171,8 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
     }
     const float cc = r[2 * (NB - 1)], sc = r[2 * (NB - 1) + 1];
     d[NB - 1] = cp_grad<L, Q0, Q1>(st);
-    cp_apply<L, Q0, Q1>(st.pr, st.pi, cc, -sc, st);
-    cp_apply<L, Q0, Q1>(st.cr, st.ci, cc, -sc, st);
+    cp_apply<L, Q0, Q1>(st.p, cc, -sc, st);
+    cp_apply<L, Q0, Q1>(st.c, cc, -sc, st);
     gate_fence<L>();
 }
 
@@ -191,11 +186,11 @@ __device__ __forceinline__ void surface_bwd_independent(const State<L>& st, cons
         constexpr int Q = decltype(qq)::value;
         State<L> s = st;
         ds[3 * Q + 2] = rot_grad<L, OP_RZ, Q>(s);
-        rot_apply<L, OP_RZ, Q>(s.pr, s.pi, sr[6 * Q + 4], -sr[6 * Q + 5], s);
-        rot_apply<L, OP_RZ, Q>(s.cr, s.ci, sr[6 * Q + 4], -sr[6 * Q + 5], s);
+        rot_apply<L, OP_RZ, Q>(s.p, sr[6 * Q + 4], -sr[6 * Q + 5], s);
+        rot_apply<L, OP_RZ, Q>(s.c, sr[6 * Q + 4], -sr[6 * Q + 5], s);
         ds[3 * Q + 1] = rot_grad<L, OP_RX, Q>(s);
-        rot_apply<L, OP_RX, Q>(s.pr, s.pi, sr[6 * Q + 2], -sr[6 * Q + 3], s);
-        rot_apply<L, OP_RX, Q>(s.cr, s.ci, sr[6 * Q + 2], -sr[6 * Q + 3], s);
+        rot_apply<L, OP_RX, Q>(s.p, sr[6 * Q + 2], -sr[6 * Q + 3], s);
+        rot_apply<L, OP_RX, Q>(s.c, sr[6 * Q + 2], -sr[6 * Q + 3], s);
         ds[3 * Q + 0] = rot_grad<L, OP_RZ, Q>(s);
     }, typename make_iseq<NQ>::type{});
 }
@@ -229,19 +224,19 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
     float* red = smem + Lds::red(K, WPS);
-    float2* ph = reinterpret_cast<float2*>(smem + Lds::phase(K, WPS)) + lane;      // MERGE: unit u at ph[64 * u]
+    f2* ph = reinterpret_cast<f2*>(smem + Lds::phase(K, WPS)) + lane;      // MERGE: unit u at ph[64 * u]
 
     State<L> st;
 #pragma unroll
-    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; }
+    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; st.sgp[i] = f2{1.f, st.sg[i]}; }
     const int col = L::col_index(lane, wave);
     // the target stays in registers for small tiles; with 16+ elements per thread it is re-read from
     // L2 once per step (2 x 8 E bytes per thread per ~1e5 cycles) to keep the kernel out of scratch
     constexpr bool KEEP_V = (E <= 4);
-    float vr[KEEP_V ? E : 1], vi[KEEP_V ? E : 1];
+    f2 vt[KEEP_V ? E : 1];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        if constexpr (KEEP_V) { const float2 t = a.target[L::row_index(lane, e) * L::D + col]; vr[e] = t.x; vi[e] = t.y; }
+        if constexpr (KEEP_V) { const float2 t = a.target[L::row_index(lane, e) * L::D + col]; vt[e] = f2{t.x, t.y}; }
     }
     const int dst_lane = reduce8_dst_lane(lane);
 
@@ -302,7 +297,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         CPF_STAMP(7)
         // ================= forward
 #pragma unroll
-        for (int e = 0; e < E; e++) { st.pr[e] = (L::row_index(lane, e) == col) ? 1.f : 0.f; st.pi[e] = 0.f; }
+        for (int e = 0; e < E; e++) st.p[e] = f2{(L::row_index(lane, e) == col) ? 1.f : 0.f, 0.f};
         {
             // two record buffers used alternately with a compile-time parity (no register copies): a body
             // covers UNR blocks = one layer, or two layers when the layer length is odd.  The first block
@@ -316,9 +311,9 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             if constexpr (E < 16) { if (K > 0) load_rec(smem + Lds::BLK_CS, ra); }
             static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
                 constexpr int Q = decltype(qq)::value;
-                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q], sr[6 * Q + 1], st);
-                rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
-                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
+                rot_apply<L, OP_RZ, Q>(st.p, sr[6 * Q], sr[6 * Q + 1], st);
+                rot_apply<L, OP_RX, Q>(st.p, sr[6 * Q + 2], sr[6 * Q + 3], st);
+                rot_apply<L, OP_RZ, Q>(st.p, sr[6 * Q + 4], sr[6 * Q + 5], st);
             }, typename make_iseq<NQ>::type{});
             int b = 0;
             float pz[4] = {1.f, 0.f, 1.f, 0.f};          // MERGE: (cos, sin) of the previous block's final Rz pair
@@ -331,10 +326,10 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                     // next record first: an LDS read cannot be moved above the phase store by the compiler, and
                     // issued mid-block it returns after the next block wants it (same-box A/B on config 2: 10.19 -> 10.07 ms)
                     load_rec(smem + Lds::BLK_CS + 16 * (b + 1 < K ? b + 1 : b), nxt);
-                    const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                    const f2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                         st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
                     if constexpr (STORE) ph[64 * b] = rho;
-                    phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+                    phase_apply<L>(st.p[0], rho, false);
                     lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
 #pragma unroll
                     for (int i = 0; i < 4; i++) pz[i] = cur[4 * (NR - 1) + i];
@@ -360,10 +355,10 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                     static_for([&](auto jj) __attribute__((always_inline)) {
                         constexpr int J = decltype(jj)::value, I = J % LL;
                         if (J == jt) {
-                            const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                            const f2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                                 st, pz[0], pz[1], pz[2], pz[3], 1.f, 0.f);
                             if constexpr (STORE) ph[64 * K] = rho;
-                            phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+                            phase_apply<L>(st.p[0], rho, false);
                         }
                     }, typename make_iseq<UNR>::type{});
                 }
@@ -372,16 +367,20 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         CPF_STAMP(1)                                  // forward blocks done
         // ================= loss, penalty, best tracking
         float acc[3] = {0.f, 0.f, 0.f};
+        {
+            f2 tt = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            float2 t;
-            if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
-            if (a.loss_kind == 2) {                   // relative phase: sum |V|^2 |psi|^2
-                acc[0] = fmaf(fmaf(t.x, t.x, t.y * t.y), fmaf(st.pr[e], st.pr[e], st.pi[e] * st.pi[e]), acc[0]);
-            } else {                                  // T = sum psi conj(V)
-                acc[0] = fmaf(st.pr[e], t.x, acc[0]); acc[0] = fmaf(st.pi[e], t.y, acc[0]);
-                acc[1] = fmaf(st.pi[e], t.x, acc[1]); acc[1] = fmaf(-st.pr[e], t.y, acc[1]);
+            for (int e = 0; e < E; e++) {
+                f2 t;
+                if constexpr (KEEP_V) t = vt[e]; else { const float2 g = a.target[L::row_index(lane, e) * L::D + col]; t = f2{g.x, g.y}; }
+                if (a.loss_kind == 2) {               // relative phase: sum |V|^2 |psi|^2
+                    acc[0] = fmaf(fmaf(t.x, t.x, t.y * t.y), fmaf(st.p[e].x, st.p[e].x, st.p[e].y * st.p[e].y), acc[0]);
+                } else {                              // T = sum psi conj(V)
+                    tt = pk_fma(splat(t.x), st.p[e], tt);
+                    tt = pk_fma(f2{t.y, -t.y}, swp(st.p[e]), tt);
+                }
             }
+            if (a.loss_kind != 2) { acc[0] = tt.x; acc[1] = tt.y; }
         }
         if (a.use_reg) {
 #pragma unroll
@@ -413,15 +412,13 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                float2 t;
-                if constexpr (KEEP_V) t = make_float2(vr[e], vi[e]); else t = a.target[L::row_index(lane, e) * L::D + col];
+                f2 t;
+                if constexpr (KEEP_V) t = vt[e]; else { const float2 g = a.target[L::row_index(lane, e) * L::D + col]; t = f2{g.x, g.y}; }
                 if (a.loss_kind == 2) {
                     const float w = -a.inv_dim2 * fmaf(t.x, t.x, t.y * t.y);
-                    st.cr[e] = w * st.pr[e];
-                    st.ci[e] = w * st.pi[e];
+                    st.c[e] = splat(w) * st.p[e];
                 } else {
-                    st.cr[e] = fmaf(fr, t.x, -fi * t.y);
-                    st.ci[e] = fmaf(fr, t.y, fi * t.x);
+                    st.c[e] = cmul(t, f2{fr, fi});
                 }
             }
         }
@@ -433,7 +430,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
             if constexpr (E < 16) load_rec(smem + Lds::BLK_CS + 16 * b, ra);      // record of block K-1
             if constexpr (MERGE) {
                 const int jt = (K - 1) % UNR;
-                float2 rho = make_float2(1.f, 0.f);
+                f2 rho = {1.f, 0.f};
                 if constexpr (STORE) rho = ph[64 * K];
                 static_for([&](auto jj) __attribute__((always_inline)) {
                     constexpr int J = decltype(jj)::value, I = J % LL;
@@ -441,19 +438,19 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                         if constexpr (!STORE)
                             rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                                 st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
-                        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+                        const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);
                         dzu = -st.sg[PL::v[2 * I]] * w;
                         dzd = -st.sg[PL::v[2 * I + 1]] * w;
                     }
                 }, typename make_iseq<UNR>::type{});
-                phase_apply<L>(st.pr[0], st.pi[0], rho, true);
-                phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+                phase_apply<L>(st.p[0], rho, true);
+                phase_apply<L>(st.c[0], rho, true);
             }
             // one block of the backward sweep; CUR = its record
             auto bwd_block = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
                 constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
                 if constexpr (MERGE) {
-                    float2 rho;
+                    f2 rho;
                     if constexpr (STORE) rho = ph[64 * b];
 #pragma unroll
                     for (int k = 0; k < 8; k++) d[k] = 0.f;
@@ -466,14 +463,14 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                             cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
                     }
                     d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
-                    const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);     // shared by CP(b), Rz(up), Rz(dn) of block b-1
+                    const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);     // shared by CP(b), Rz(up), Rz(dn) of block b-1
                     constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
                     constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
                     d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
                     dzu = -st.sg[PL::v[2 * IP]] * w;
                     dzd = -st.sg[PL::v[2 * IP + 1]] * w;
-                    phase_apply<L>(st.pr[0], st.pi[0], rho, true);
-                    phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+                    phase_apply<L>(st.p[0], rho, true);
+                    phase_apply<L>(st.c[0], rho, true);
                 } else {
                     lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, d);
                 }

@@ -64,28 +64,28 @@ template <int ROT> __host__ __device__ constexpr int inner_gates() { return 2 * 
 
 // forward inner rotations of a block on psi, psi stored after each gate: slot[64 g]
 template <class L, int UP, int DN, int ROT>
-__device__ __forceinline__ void lay_block_fwd_inner_store(State<L>& st, const float (&r)[16], float2* slot) {
+__device__ __forceinline__ void lay_block_fwd_inner_store(State<L>& st, const float (&r)[16], f2* slot) {
     static_for([&](auto gg) __attribute__((always_inline)) {
         constexpr int G = decltype(gg)::value;
         using IG = InnerGate<ROT, G>;
-        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.pr, st.pi, r[IG::CS], r[IG::CS + 1], st);
-        slot[64 * G] = make_float2(st.pr[0], st.pi[0]);
+        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.p, r[IG::CS], r[IG::CS + 1], st);
+        slot[64 * G] = st.p[0];
     }, typename make_iseq<inner_gates<ROT>()>::type{});
 }
 // inverse inner rotations of a block on psi, psi stored BEFORE each un-application (= the state after that gate)
 template <class L, int UP, int DN, int ROT>
-__device__ __forceinline__ void lay_block_inv_inner_store(State<L>& st, const float (&r)[16], float2* slot) {
+__device__ __forceinline__ void lay_block_inv_inner_store(State<L>& st, const float (&r)[16], f2* slot) {
     static_for([&](auto gg) __attribute__((always_inline)) {
         constexpr int G = inner_gates<ROT>() - 1 - decltype(gg)::value;
         using IG = InnerGate<ROT, G>;
-        slot[64 * G] = make_float2(st.pr[0], st.pi[0]);
-        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.pr, st.pi, r[IG::CS], -r[IG::CS + 1], st);
+        slot[64 * G] = st.p[0];
+        rot_apply<L, IG::KIND, IG::template qubit<UP, DN>()>(st.p, r[IG::CS], -r[IG::CS + 1], st);
     }, typename make_iseq<inner_gates<ROT>()>::type{});
 }
 
 // ---- wave A forward: blocks [0, n) applied to psi; units (merged diagonal runs) 0 .. n stored at ph[64 u]
 template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false>
-__device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n, float2* ph, float2* sp = nullptr) {
+__device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n, f2* ph, f2* sp = nullptr) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     float ra[16], rb[16];
     float pz[4] = {1.f, 0.f, 1.f, 0.f};
@@ -96,10 +96,10 @@ __device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n,
         float (&cur)[16] = (J & 1) ? rb : ra;
         float (&nxt)[16] = (J & 1) ? ra : rb;
         load_rec(rec + 16 * (b + 1 < n ? b + 1 : b), nxt);
-        const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+        const f2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
             st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
         if constexpr (STORE) ph[64 * b] = rho;
-        phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+        phase_apply<L>(st.p[0], rho, false);
         if constexpr (PS) lay_block_fwd_inner_store<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, sp + 64 * (NI * b + 1));
         else lay_block_fwd_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
 #pragma unroll
@@ -113,10 +113,10 @@ __device__ __forceinline__ void split_fwd(State<L>& st, const float* rec, int n,
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
             if (J == jt) {
-                const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                const f2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                     st, pz[0], pz[1], pz[2], pz[3], 1.f, 0.f);
                 if constexpr (STORE) ph[64 * n] = rho;
-                phase_apply<L>(st.pr[0], st.pi[0], rho, false);
+                phase_apply<L>(st.p[0], rho, false);
             }
         }, typename make_iseq<UNR>::type{});
     }
@@ -129,18 +129,18 @@ __device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&
 #pragma unroll
     for (int i = NR - 2; i >= 0; i--) {
         if (rot_kind(ROT, i) == OP_RX) {
-            rot_apply<L, OP_RX, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RX, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+            rot_apply<L, OP_RX, DN>(st.p, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RX, UP>(st.p, r[4 * i], -r[4 * i + 1], st);
         } else if (rot_kind(ROT, i) == OP_RY) {
-            rot_apply<L, OP_RY, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RY, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+            rot_apply<L, OP_RY, DN>(st.p, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RY, UP>(st.p, r[4 * i], -r[4 * i + 1], st);
         } else {
-            rot_apply<L, OP_RZ, DN>(st.pr, st.pi, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RZ, UP>(st.pr, st.pi, r[4 * i], -r[4 * i + 1], st);
+            rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], -r[4 * i + 3], st); rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], -r[4 * i + 1], st);
         }
     }
 }
 
 // ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
 template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false>
-__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, float2* ph, float2* sp = nullptr) {
+__device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, f2* ph, f2* sp = nullptr) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     float ra[16], rb[16];
     int b = n - 1;
@@ -150,10 +150,10 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
             if (J == jt) {
-                const float2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+                const f2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                     st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
                 if constexpr (STORE) ph[64 * n] = rho;
-                phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+                phase_apply<L>(st.p[0], rho, true);
             }
         }, typename make_iseq<UNR>::type{});
     }
@@ -161,11 +161,11 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
         constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
         if constexpr (PS) lay_block_inv_inner_store<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, sp + 64 * (NI * b + 1));
         else lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
-        const float2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
+        const f2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
             st, prv[4 * (NR - 1)], prv[4 * (NR - 1) + 1], prv[4 * (NR - 1) + 2], prv[4 * (NR - 1) + 3],
             cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
         if constexpr (STORE) ph[64 * b] = rho;
-        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
+        phase_apply<L>(st.p[0], rho, true);
         b--;
     };
     const int tail = n % UNR;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
 
 // ---- wave A backward: blocks n-1 .. 0 un-applied from psi and C, gradients to gblk[32 b] (as cpf_layered.h)
 template <class L, class PL, int LL, int ROT, bool STORE>
-__device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, int n, const float2* ph, float* gblk,
+__device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, int n, const f2* ph, float* gblk,
                                                int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
     if (n <= 0) return;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
     load_rec(rec + 16 * b, ra);
     {
         const int jt = (n - 1) % UNR;
-        float2 rho = make_float2(1.f, 0.f);
+        f2 rho = {1.f, 0.f};
         if constexpr (STORE) rho = ph[64 * n];
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
@@ -211,17 +211,17 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
                 if constexpr (!STORE)
                     rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                         st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
-                const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+                const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);
                 dzu = -st.sg[PL::v[2 * I]] * w;
                 dzd = -st.sg[PL::v[2 * I + 1]] * w;
             }
         }, typename make_iseq<UNR>::type{});
-        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
-        phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+        phase_apply<L>(st.p[0], rho, true);
+        phase_apply<L>(st.c[0], rho, true);
     }
     auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
         constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
-        float2 rho;
+        f2 rho;
         if constexpr (STORE) rho = ph[64 * b];
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = 0.f;
@@ -234,14 +234,14 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
                 cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
         }
         d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
-        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);
+        const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);
         constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
         constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
         d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
         dzu = -st.sg[PL::v[2 * IP]] * w;
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
-        phase_apply<L>(st.pr[0], st.pi[0], rho, true);
-        phase_apply<L>(st.cr[0], st.ci[0], rho, true);
+        phase_apply<L>(st.p[0], rho, true);
+        phase_apply<L>(st.c[0], rho, true);
         reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
         b--;
     };
@@ -271,8 +271,8 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
 // a rotation applied to psi and C, then its gradient (psi_j, C_j right after the gate)
 template <class L, int KIND, int Q>
 __device__ __forceinline__ float lay_rot_fwd_grad(State<L>& st, float c, float s) {
-    rot_apply<L, KIND, Q>(st.pr, st.pi, c, s, st);
-    rot_apply<L, KIND, Q>(st.cr, st.ci, c, s, st);
+    rot_apply<L, KIND, Q>(st.p, c, s, st);
+    rot_apply<L, KIND, Q>(st.c, c, s, st);
     return rot_grad<L, KIND, Q>(st);
 }
 template <class L, int UP, int DN, int ROT>
@@ -294,7 +294,7 @@ __device__ __forceinline__ void lay_block_fwd_grad_inner(State<L>& st, const flo
 // Unit b carries the CP of block b and the final Rz pair of block b-1, so block b-1's eight partials are complete
 // — and scattered — at unit b.
 template <class L, class PL, int LL, int ROT, bool STORE>
-__device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, int n, const float2* ph, float* gblk,
+__device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, int n, const f2* ph, float* gblk,
                                                int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
     float ra[16], rb[16], da[8], db[8];
@@ -310,13 +310,13 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
         float (&dcur)[8] = (J & 1) ? db : da;
         float (&dprv)[8] = (J & 1) ? da : db;
         load_rec(rec + 16 * (b + 1 < n ? b + 1 : b), nxt);
-        float2 rho;
+        f2 rho;
         if constexpr (STORE) rho = ph[64 * b];
         else rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                  st, pz[0], pz[1], pz[2], pz[3], cur[2 * (NB - 1)], cur[2 * (NB - 1) + 1]);
-        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);      // invariant under the run's common phase
-        phase_apply<L>(st.pr[0], st.pi[0], rho, false);
-        phase_apply<L>(st.cr[0], st.ci[0], rho, false);
+        const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);      // invariant under the run's common phase
+        phase_apply<L>(st.p[0], rho, false);
+        phase_apply<L>(st.c[0], rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
         if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
@@ -336,7 +336,7 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
     static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
     {
         const int jt = (n - 1) % UNR;
-        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);      // last unit: only its gradient is needed
+        const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);      // last unit: only its gradient is needed
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
             if (J == jt) {
@@ -356,9 +356,9 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
 // onto psi once).  Per block 4 x (4 + 3) + 13 VALU operations instead of 4 x (8 + 3) + 15, for NI + 1 more
 // ds_read_b64 / NI more ds_write_b64, prefetched one block ahead; no float32 drift from un-applying psi.
 template <int NI>
-struct BlkBuf { float r[16]; float2 x[NI > 0 ? NI : 1]; float2 rho; };
+struct BlkBuf { float r[16]; f2 x[NI > 0 ? NI : 1]; f2 rho; };
 template <int NI>
-__device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const float2* slots, const float2* ph) {
+__device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const f2* slots, const f2* ph) {
     load_rec(rec, q.r);
 #pragma unroll
     for (int j = 0; j < NI; j++) q.x[j] = slots[64 * j];
@@ -366,28 +366,28 @@ __device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const 
 }
 
 // ---- wave A backward: blocks n-1 .. 0 un-applied from C only.  Slot NI b + 1 + g = psi after inner gate g of
-// block b, slot 0 = psi after the surface gates; on exit st.pr / st.pi hold that slot-0 state.
+// block b, slot 0 = psi after the surface gates; on exit st.p holds that slot-0 state.
 template <class L, class PL, int LL, int ROT>
-__device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec, int n, const float2* ph, const float2* sp,
+__device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec, int n, const f2* ph, const f2* sp,
                                                   float* gblk, int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
     BlkBuf<NI> qa, qb;
     float d[8];
     int b = n - 1;
-    float2 held = sp[64 * NI * n];                              // psi after the last inner gate of block n-1
-    const float2 rho_n = ph[64 * n];
+    f2 held = sp[64 * NI * n];                              // psi after the last inner gate of block n-1
+    const f2 rho_n = ph[64 * n];
     if (b & 1) load_blk(qb, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
     else load_blk(qa, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
     float dzu = 0.f, dzd = 0.f;
     {
         const int jt = (n - 1) % UNR;
-        const float w = fmaf(st.cr[0], st.pi[0], -st.ci[0] * st.pr[0]);   // psi, C after unit n (registers)
+        const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);   // psi, C after unit n (registers)
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
             if (J == jt) { dzu = -st.sg[PL::v[2 * I]] * w; dzd = -st.sg[PL::v[2 * I + 1]] * w; }
         }, typename make_iseq<UNR>::type{});
-        phase_apply<L>(st.cr[0], st.ci[0], rho_n, true);
+        phase_apply<L>(st.c[0], rho_n, true);
     }
     auto blk = [&](auto jj, BlkBuf<NI>& cur, BlkBuf<NI>& nxt) __attribute__((always_inline)) {
         constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
@@ -400,15 +400,13 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
             constexpr int G = NI - 1 - decltype(gg)::value;
             using IG = InnerGate<ROT, G>;
             constexpr int Q = IG::template qubit<UP, DN>();
-            float2 ps;
-            if constexpr (G == NI - 1) ps = held; else ps = cur.x[G + 1];
-            st.pr[0] = ps.x; st.pi[0] = ps.y;
+            if constexpr (G == NI - 1) st.p[0] = held; else st.p[0] = cur.x[G + 1];
             d[G] = rot_grad<L, IG::KIND, Q>(st);
-            rot_apply<L, IG::KIND, Q>(st.cr, st.ci, cur.r[IG::CS], -cur.r[IG::CS + 1], st);
+            rot_apply<L, IG::KIND, Q>(st.c, cur.r[IG::CS], -cur.r[IG::CS + 1], st);
         }, typename make_iseq<NI>::type{});
-        phase_apply<L>(st.cr[0], st.ci[0], cur.rho, true);       // C now sits before unit b, where cur.x[0] was stored
+        phase_apply<L>(st.c[0], cur.rho, true);       // C now sits before unit b, where cur.x[0] was stored
         held = cur.x[0];
-        const float w = fmaf(st.cr[0], held.y, -st.ci[0] * held.x);
+        const float w = fmaf(st.c[0].x, held.y, -st.c[0].y * held.x);
         d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
         constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
         d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
@@ -427,14 +425,14 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
             constexpr int J = UNR - 1 - decltype(jj)::value;
             if constexpr (J & 1) blk(ic<J>{}, qb, qa); else blk(ic<J>{}, qa, qb);
         }, typename make_iseq<UNR>::type{});
-    st.pr[0] = held.x; st.pi[0] = held.y;
+    st.p[0] = held;
 }
 
 // ---- wave B backward: blocks 0 .. n-1 applied to psi' = conj(f) H1 only.  held = W at the cut on entry;
 // slot NI b + 1 + g = W after inner gate g of (local) block b.
 template <class L, class PL, int LL, int ROT>
-__device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, float2 held, const float* rec, int n, const float2* ph,
-                                                  const float2* sp, float* gblk, int lane, int dst_lane) {
+__device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const float* rec, int n, const f2* ph,
+                                                  const f2* sp, float* gblk, int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
     BlkBuf<NI> qa, qb;
@@ -452,8 +450,8 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, float2 held, con
         float (&dprv)[8] = (J & 1) ? da : db;
         const int bn = b + 1 < n ? b + 1 : b;
         load_blk(nxt, rec + 16 * bn, sp + 64 * (NI * bn + 1), ph + 64 * bn);
-        const float w = fmaf(held.x, st.pi[0], -held.y * st.pr[0]);          // W, psi' before unit b
-        phase_apply<L>(st.pr[0], st.pi[0], cur.rho, false);
+        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);          // W, psi' before unit b
+        phase_apply<L>(st.p[0], cur.rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
         if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
@@ -465,8 +463,8 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, float2 held, con
             constexpr int G = decltype(gg)::value;
             using IG = InnerGate<ROT, G>;
             constexpr int Q = IG::template qubit<UP, DN>();
-            rot_apply<L, IG::KIND, Q>(st.pr, st.pi, cur.r[IG::CS], cur.r[IG::CS + 1], st);
-            st.cr[0] = cur.x[G].x; st.ci[0] = cur.x[G].y;
+            rot_apply<L, IG::KIND, Q>(st.p, cur.r[IG::CS], cur.r[IG::CS + 1], st);
+            st.c[0] = cur.x[G];
             dcur[G] = rot_grad<L, IG::KIND, Q>(st);
         }, typename make_iseq<NI>::type{});
         held = cur.x[NI - 1];
@@ -476,7 +474,7 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, float2 held, con
     static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
     {
         const int jt = (n - 1) % UNR;
-        const float w = fmaf(held.x, st.pi[0], -held.y * st.pr[0]);          // last unit: the Rz pair of block n-1
+        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);          // last unit: the Rz pair of block n-1
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
             if (J == jt) {
@@ -521,15 +519,16 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
     float* gs = smem + Lds::slab(K);
     float* red = smem + Lds::red(K);
-    float2* xch = reinterpret_cast<float2*>(smem + Lds::xch(K)) + lane;                 // [0]: psi of wave A, [64]: W of wave B
-    float2* ph = reinterpret_cast<float2*>(smem + Lds::phase(K)) + lane + (wave ? 64 * (m + 1) : 0);
-    float2* sp = reinterpret_cast<float2*>(smem + Lds::states(K)) + lane + (wave ? 64 * (NI * m + 1) : 0);
+    f2* xch = reinterpret_cast<f2*>(smem + Lds::xch(K)) + lane;                 // [0]: psi of wave A, [64]: W of wave B
+    f2* ph = reinterpret_cast<f2*>(smem + Lds::phase(K)) + lane + (wave ? 64 * (m + 1) : 0);
+    f2* sp = reinterpret_cast<f2*>(smem + Lds::states(K)) + lane + (wave ? 64 * (NI * m + 1) : 0);
 
     State<L> st;
 #pragma unroll
-    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; }
+    for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; st.sgp[i] = f2{1.f, st.sg[i]}; }
     const int col = L::col_index(lane, 0);
-    const float2 vt = a.target[L::row_index(lane, 0) * L::D + col];
+    const float2 vt_ = a.target[L::row_index(lane, 0) * L::D + col];
+    const f2 vt = {vt_.x, vt_.y};
     const int dst_lane = reduce8_dst_lane(lane);
 
     // ---- owner state.  Owner slot o = tid + 128 s; the K <= 64 CP angles come first (all in wave 0, slot 0).
@@ -593,7 +592,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         // ================= forward: A builds H1 from the identity, B builds W = H2^+ V
         if (wave == 0) {
             if (a.use_reg) { pen_sum = wave_sum(pval[0]); red[0] = pen_sum; }
-            st.pr[0] = (L::row_index(lane, 0) == col) ? 1.f : 0.f; st.pi[0] = 0.f;
+            st.p[0] = f2{(L::row_index(lane, 0) == col) ? 1.f : 0.f, 0.f};
             float sr[Lds::SURF_F];
 #pragma unroll
             for (int i = 0; i < Lds::SURF_F / 4; i++) {
@@ -602,26 +601,27 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
             static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
                 constexpr int Q = decltype(qq)::value;
-                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q], sr[6 * Q + 1], st);
-                rot_apply<L, OP_RX, Q>(st.pr, st.pi, sr[6 * Q + 2], sr[6 * Q + 3], st);
-                rot_apply<L, OP_RZ, Q>(st.pr, st.pi, sr[6 * Q + 4], sr[6 * Q + 5], st);
+                rot_apply<L, OP_RZ, Q>(st.p, sr[6 * Q], sr[6 * Q + 1], st);
+                rot_apply<L, OP_RX, Q>(st.p, sr[6 * Q + 2], sr[6 * Q + 3], st);
+                rot_apply<L, OP_RZ, Q>(st.p, sr[6 * Q + 4], sr[6 * Q + 5], st);
             }, typename make_iseq<NQ>::type{});
-            if constexpr (PS) sp[0] = make_float2(st.pr[0], st.pi[0]);
+            if constexpr (PS) sp[0] = st.p[0];
             split_fwd<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS, m, ph, sp);
-            xch[0] = make_float2(st.pr[0], st.pi[0]);
+            xch[0] = st.p[0];
         } else {
-            st.pr[0] = vt.x; st.pi[0] = vt.y;
+            st.p[0] = vt;
             split_inv<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
-            xch[64] = make_float2(st.pr[0], st.pi[0]);
+            xch[64] = st.p[0];
         }
         CPF_STAMP(0)                                  // forward half done
         split_barrier();
         CPF_STAMP(1)                                  // waited for the other wave
         // ================= loss (both waves, identical arithmetic), best tracking
-        float wr, wi;
-        if (wave == 0) { const float2 o = xch[64]; wr = o.x; wi = o.y; }
-        else { const float2 o = xch[0]; wr = st.pr[0]; wi = st.pi[0]; st.pr[0] = o.x; st.pi[0] = o.y; if (a.use_reg) pen_sum = red[0]; }
-        float tr = fmaf(st.pi[0], wi, st.pr[0] * wr), ti = fmaf(-st.pr[0], wi, st.pi[0] * wr);     // T = sum psi conj(W)
+        f2 w;                                         // W = H2^+ V at the cut
+        if (wave == 0) w = xch[64];
+        else { w = st.p[0]; st.p[0] = xch[0]; if (a.use_reg) pen_sum = red[0]; }
+        const f2 tt = cmul_conj(st.p[0], w);          // T = sum psi conj(W)
+        float tr = tt.x, ti = tt.y;
         wave_sum2(tr, ti);
         // wave A alone turns T into the loss and tracks the best iterate; wave B needs only T (for the cotangent)
         // and, at its owner phase, A's verdict on whether this iterate is the best so far (red[1])
@@ -650,13 +650,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         // ================= backward: C = f W at the cut
         {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
-            if (!PS || wave == 0) {
-                st.cr[0] = fmaf(fr, wr, -fi * wi);
-                st.ci[0] = fmaf(fr, wi, fi * wr);
-            } else {                                  // wave B, stored states: f moves onto psi
-                const float qr = fmaf(fr, st.pr[0], fi * st.pi[0]), qi = fmaf(fr, st.pi[0], -fi * st.pr[0]);
-                st.pr[0] = qr; st.pi[0] = qi;
-            }
+            if (!PS || wave == 0) st.c[0] = cmul(w, f2{fr, fi});
+            else st.p[0] = cmul_conj(st.p[0], f2{fr, fi});      // wave B, stored states: f moves onto psi
         }
         if (wave == 0) {
             if constexpr (PS) split_bwd_grad_ps<L, PL, LL, ROT>(st, smem + Lds::BLK_CS, m, ph, sp, gs + 32 * Lds::NBATCH, lane, dst_lane);
@@ -679,7 +674,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
         } else {
             if constexpr (PS)
-                split_fwd_grad_ps<L, PL, LL, ROT>(st, make_float2(wr, wi), smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
+                split_fwd_grad_ps<L, PL, LL, ROT>(st, w, smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
                                                   gs + 32 * Lds::NBATCH + 32 * m, lane, dst_lane);
             else
                 split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
