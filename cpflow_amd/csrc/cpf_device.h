@@ -463,9 +463,32 @@ __device__ __forceinline__ float floor_mod_2pi(float a) {
     const float twopi = 6.2831855f;
     const float k = floorf(a * 0.15915494f);
     float r = fmaf(-k, twopi, a);
-    if (r < 0.f) r += twopi;
-    else if (r >= twopi) r -= twopi;
+    r = (r < 0.f) ? r + twopi : r;                        // selects, not branches: the owner phase is on every
+    r = (r >= twopi) ? r - twopi : r;                     // step's critical path
     return r;
+}
+// sin and cos of one angle for the gate records: Cody-Waite reduction by pi/2 (three-term constant, exact
+// products through fma: good for |x| < ~1e5, far beyond where Adam takes an angle) and the cephes single-precision
+// polynomials on [-pi/4, pi/4]; <= 1 ulp of the result scale (max abs error 9e-8 over |x| < 1e4 against float64; every unitary / loss parity test runs through it).
+// ~25 instructions and no branch, against ~100 with a large-argument path for the device library's sincosf.
+__device__ __forceinline__ void fast_sincos(float x, float& sn, float& cn) {
+    const float k = rintf(x * 0.636619772f);
+    float r = fmaf(-k, 1.57079637f, x);
+    r = fmaf(-k, -4.37113883e-8f, r);
+    r = fmaf(-k, -1.71512489e-15f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s0 = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c0 = fmaf(pc, z * z, fmaf(-0.5f, z, 1.f));
+    const int q = (int)k;
+    const bool odd = q & 1;
+    const float s1 = odd ? c0 : s0, c1 = odd ? s0 : c0;
+    // quadrant signs: sin negative for q mod 4 in {2, 3}, cos negative for {1, 2}
+    sn = __uint_as_float(__float_as_uint(s1) ^ (((unsigned)q & 2u) << 30));
+    cn = __uint_as_float(__float_as_uint(c1) ^ ((((unsigned)q + 1u) & 2u) << 30));
 }
 // LDS copy of the piece table: 8 lower break points (pieces 1..8), then 9 x (slope, intercept); 28 floats.
 // Selecting among kernel-argument fields made hipcc select the field ADDRESS and issue a per-lane global
@@ -612,7 +635,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
     auto publish = [&](int j, float t) {
         float sn, cn;
         const bool cp = a.pkind[j];
-        sincosf(cp ? t : 0.5f * t, &sn, &cn);
+        fast_sincos(cp ? t : 0.5f * t, sn, cn);
         float2* r = reinterpret_cast<float2*>(&rec[a.pgate[j]]);
         *r = make_float2(cn, sn);
     };

@@ -276,7 +276,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         float2 si = make_float2(0.f, 0.f);
         if (lin) { x = floor_mod_2pi(th[s]); si = penalty_lookup(smem, x); }
         float sn, cn;
-        sincosf(is_cp[s] ? th[s] : 0.5f * th[s], &sn, &cn);       // 3.4 % of config 2's kernel time
+        fast_sincos(is_cp[s] ? th[s] : 0.5f * th[s], sn, cn);       // 3.4 % of config 2's kernel time
         if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
         if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
         else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }

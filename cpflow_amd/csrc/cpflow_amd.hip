@@ -140,18 +140,22 @@ bool phases_fit(int num_cu, int64_t S, size_t lds_bytes_with_phases) {
 }
 // Two waves per sample (cpf_split.h) while the one-wave kernel would leave SIMDs with a single wave: the step is
 // then one exposed dependent chain, and cutting it in two is worth more than the second wave's issue slots.
-bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int rot_code, int64_t S) {
+// With the block count a compile-time constant (kspec) the two-ended kernel also wins once the SIMDs are full
+// (config 2 shape, same box: S = 2048 15.1 vs 17.8 ms, 16384 84.2 vs 93.7 ms; config 3 shape S = 4096 28.8 vs 33.8 ms).
+bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int rot_code, int64_t S, bool kspec) {
     if (!cpf::layered_merge(3, 0, rot_code) || !cpf::split_supported(K, LL) || a.loss_kind == 2) return false;
     { const char* e = getenv("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
-    return S <= (int64_t)plan->num_cu * 4;
+    return kspec || S <= (int64_t)plan->num_cu * 4;
 }
+bool kspec_enabled() { const char* e = getenv("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
 // Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
 // them while LDS still admits the workgroups the launch wants on a CU.
 bool states_fit(int num_cu, int64_t S, int rot_code, size_t lds_bytes_with_states) {
     if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > 64 * 1024) return false;
     { const char* e = getenv("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
-    const int64_t want = std::min<int64_t>((S + num_cu - 1) / num_cu, 4);
-    return (int64_t)(160 * 1024 / lds_bytes_with_states) >= want;
+    // only while every workgroup of the launch is resident at once (same box, config 2 shape: S = 1024 6.95 vs 7.15 ms
+    // with / without states, S = 2048 17.5 vs 15.1, S = 4096 32.1 vs 22.8)
+    return (int64_t)(160 * 1024 / lds_bytes_with_states) >= (S + num_cu - 1) / num_cu;
 }
 // K-specialised two-ended kernels exist ahead of time for the BASELINE 3-qubit configurations
 // (chain_layer(3) with 12 blocks, connected_layer(3) with 16; 'xyz'); KC = 0: K is read from the plan.
@@ -177,13 +181,12 @@ template <int ROT, int PPT, int... UD>
 int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
     cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
     plan->variant = "layered/aot waves=1";
-    if (want_split(plan, a, K, (int)sizeof...(UD) / 2, ROT, S)) {
-        constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
-        constexpr int LL = (int)sizeof...(UD) / 2;
-        const char* e = getenv("CPF_KSPEC");                                       // A/B and tests: 0 = K from the plan
-        const bool kspec = !(e && e[0] == '0');
-        if constexpr (ROT == XYZ && PPT == 2 && LL == 2) { if (kspec && K == 12) return launch_split3<ROT, PPT / 2, 12, UD...>(plan, a, K, S, stream); }
-        if constexpr (ROT == XYZ && PPT == 2 && LL == 3) { if (kspec && K == 16) return launch_split3<ROT, PPT / 2, 16, UD...>(plan, a, K, S, stream); }
+    constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
+    constexpr int LL = (int)sizeof...(UD) / 2;
+    const bool kspec = kspec_enabled() && ROT == XYZ && PPT == 2 && ((LL == 2 && K == 12) || (LL == 3 && K == 16));
+    if (want_split(plan, a, K, LL, ROT, S, kspec)) {
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 2) { if (kspec) return launch_split3<ROT, PPT / 2, 12, UD...>(plan, a, K, S, stream); }
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 3) { if (kspec) return launch_split3<ROT, PPT / 2, 16, UD...>(plan, a, K, S, stream); }
         return launch_split3<ROT, PPT / 2, 0, UD...>(plan, a, K, S, stream);
     }
     const bool merge = cpf::layered_merge(3, 0, ROT);
@@ -260,11 +263,12 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     const int rot_code = cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]);
     size_t lds = 0;
     int mstore = 0;
-    if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S)) {
+    const char* jk = getenv("CPF_JIT_K");                                        // opt-in: one build per block count
+    const bool jit_k = jk && jk[0] == '1';
+    if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = (a.P + 127) / 128;
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
-        const char* jk = getenv("CPF_JIT_K");                                    // opt-in: one build per block count
-        const int smstore = (states_fit(plan->num_cu, S, rot_code, slds2) ? 2 : 1) + ((jk && jk[0] == '1') ? 4 * plan->K : 0);
+        const int smstore = (states_fit(plan->num_cu, S, rot_code, slds2) ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
         const size_t slds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
         std::string serr;
         hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, smstore, plan->layer_ud, &serr, true) : nullptr;

@@ -316,7 +316,8 @@ def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypat
     assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 5 * tol
     assert np.abs(out['history_params'] - ref['history_params'])[:, :3].max() < 10 * tol
     assert (out['params'][:, 0] == init).all()
-    assert np.abs(out['reg'] - ref['reg']).max() < 1e-6
+    assert np.abs(out['reg'][:, 0] - ref['reg'][:, 0]).max() < 1e-6            # at the initial angles: the penalty itself
+    assert np.abs(out['reg'][:, 1] - ref['reg'][:, 1]).max() < tol / 10        # at the best iterate: + 14 steps of drift
     assert (out['cz'] == ref['cz']).all()
     # frozen angles stay put, the others move (the verification stage's use of the kernel)
     frozen = np.zeros((S, orc.P), np.uint8)
