@@ -30,6 +30,16 @@ __host__ __device__ constexpr int split_point(int K, int LL) {
     return m < 0 ? 0 : m;
 }
 __host__ __device__ constexpr bool split_supported(int K, int LL) { return K >= 2 * LL && K >= 2 && K <= 64; }
+// With K a compile-time constant the cut need not fall on a layer boundary (wave B's pair indices carry the offset
+// m mod LL).  Instruction counts of the packed stored-state sweeps: wave A = 160 (surface gates, both directions)
+// + 110 per block, wave B = 109 per block  ->  m = (109 K - 160) / 219 rounded: 5 of 12, 7 of 16.  Not the default:
+// see split_body.
+__host__ __device__ constexpr int split_point_any(int K) {
+    int m = (2 * (109 * K - 160) + 219) / (2 * 219);
+    if (m < 1) m = 1;
+    if (m > K - 1) m = K - 1;
+    return m;
+}
 
 struct SplitLds {                                          // float offsets; [0, 28) = penalty table
     using B = LayeredLds<3>;
@@ -139,7 +149,7 @@ __device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&
 }
 
 // ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
-template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false>
+template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false, int OFF = 0>
 __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, f2* ph, f2* sp = nullptr) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     float ra[16], rb[16];
@@ -148,7 +158,7 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
     {
         const int jt = (n - 1) % UNR;
         static_for([&](auto jj) __attribute__((always_inline)) {
-            constexpr int J = decltype(jj)::value, I = J % LL;
+            constexpr int J = decltype(jj)::value, I = (J + OFF) % LL;
             if (J == jt) {
                 const f2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
                     st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
@@ -170,7 +180,7 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
     };
     const int tail = n % UNR;
     static_for([&](auto jj) __attribute__((always_inline)) {
-        constexpr int J = UNR - 1 - decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int J = UNR - 1 - decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
         if (J < tail) {
             load_rec(rec + 16 * b, ra);
             load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
@@ -179,7 +189,7 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
     }, typename make_iseq<UNR>::type{});
     if (b >= 0 && tail > 0) load_rec(rec + 16 * b, ra);
     auto step = [&](auto jj) __attribute__((always_inline)) {
-        constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
         if constexpr ((JJ & 1) == 0) {
             load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
             blk(ic<I>{}, ic<IP>{}, ra, rb);
@@ -293,7 +303,7 @@ __device__ __forceinline__ void lay_block_fwd_grad_inner(State<L>& st, const flo
 // ---- wave B backward: blocks 0 .. n-1 APPLIED to psi and C (psi = H1, C = f W on entry), gradients to gblk[32 b].
 // Unit b carries the CP of block b and the final Rz pair of block b-1, so block b-1's eight partials are complete
 // — and scattered — at unit b.
-template <class L, class PL, int LL, int ROT, bool STORE>
+template <class L, class PL, int LL, int ROT, bool STORE, int OFF = 0>
 __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, int n, const f2* ph, float* gblk,
                                                int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
@@ -304,7 +314,7 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
 #pragma unroll
     for (int k = 0; k < 8; k++) { da[k] = 0.f; db[k] = 0.f; }
     auto step = [&](auto jj) __attribute__((always_inline)) {
-        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int J = decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
         float (&cur)[16] = (J & 1) ? rb : ra;
         float (&nxt)[16] = (J & 1) ? ra : rb;
         float (&dcur)[8] = (J & 1) ? db : da;
@@ -338,7 +348,7 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
         const int jt = (n - 1) % UNR;
         const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);      // last unit: only its gradient is needed
         static_for([&](auto jj) __attribute__((always_inline)) {
-            constexpr int J = decltype(jj)::value, I = J % LL;
+            constexpr int J = decltype(jj)::value, I = (J + OFF) % LL;
             if (J == jt) {
                 float (&dl)[8] = (J & 1) ? db : da;
                 dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
@@ -430,7 +440,7 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
 
 // ---- wave B backward: blocks 0 .. n-1 applied to psi' = conj(f) H1 only.  held = W at the cut on entry;
 // slot NI b + 1 + g = W after inner gate g of (local) block b.
-template <class L, class PL, int LL, int ROT>
+template <class L, class PL, int LL, int ROT, int OFF = 0>
 __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const float* rec, int n, const f2* ph,
                                                   const f2* sp, float* gblk, int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
@@ -442,7 +452,7 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const f
 #pragma unroll
     for (int k = 0; k < 8; k++) { da[k] = 0.f; db[k] = 0.f; }
     auto step = [&](auto jj) __attribute__((always_inline)) {
-        constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
+        constexpr int J = decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
         constexpr int UP = PL::v[2 * I], DN = PL::v[2 * I + 1];
         BlkBuf<NI>& cur = (J & 1) ? qb : qa;
         BlkBuf<NI>& nxt = (J & 1) ? qa : qb;
@@ -476,7 +486,7 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const f
         const int jt = (n - 1) % UNR;
         const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);          // last unit: the Rz pair of block n-1
         static_for([&](auto jj) __attribute__((always_inline)) {
-            constexpr int J = decltype(jj)::value, I = J % LL;
+            constexpr int J = decltype(jj)::value, I = (J + OFF) % LL;
             if (J == jt) {
                 float (&dl)[8] = (J & 1) ? db : da;
                 dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
@@ -512,7 +522,15 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = KC > 0 ? NS + NB * KC : a.P, K = KC > 0 ? KC : (P - NS) / NB;
     if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
-    const int m = split_point(K, LL), kb = K - m;
+    // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
+    // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a
+    // same-box A/B (-DCPF_CUT_BALANCED builds it).
+#ifdef CPF_CUT_BALANCED
+    constexpr int MC = KC > 0 ? split_point_any(KC > 0 ? KC : 2) : 0, OFF = KC > 0 ? MC % LL : 0;
+#else
+    constexpr int MC = KC > 0 ? split_point(KC > 0 ? KC : 2, LL) : 0, OFF = 0;
+#endif
+    const int m = KC > 0 ? MC : split_point(K, LL), kb = K - m;
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
@@ -610,7 +628,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             xch[0] = st.p[0];
         } else {
             st.p[0] = vt;
-            split_inv<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
+            split_inv<L, PL, LL, ROT, STORE, PS, OFF>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
             xch[64] = st.p[0];
         }
         CPF_STAMP(0)                                  // forward half done
@@ -674,10 +692,10 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             }
         } else {
             if constexpr (PS)
-                split_fwd_grad_ps<L, PL, LL, ROT>(st, w, smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
+                split_fwd_grad_ps<L, PL, LL, ROT, OFF>(st, w, smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
                                                   gs + 32 * Lds::NBATCH + 32 * m, lane, dst_lane);
             else
-                split_fwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
+                split_fwd_grad<L, PL, LL, ROT, STORE, OFF>(st, smem + Lds::BLK_CS + 16 * m, kb, ph, gs + 32 * Lds::NBATCH + 32 * m,
                                                       lane, dst_lane);
         }
         CPF_STAMP(3)                                  // backward half done
