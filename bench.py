@@ -135,7 +135,9 @@ def main():
         alg_bytes = S_local * (8 * P + 28) + 8 * 8 * 8         # persistent model: theta0 in, best theta + scalars out
         traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_v4_pmc_summary.json')) as f:
+            import glob
+            newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))[-1]
+            with open(newest) as f:
                 traffic = json.load(f)['traffic_bytes_per_launch'] if S_local == 1024 else None
         except Exception:
             pass
