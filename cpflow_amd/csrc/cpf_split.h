@@ -549,14 +549,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     const f2 vt = {vt_.x, vt_.y};
     const int dst_lane = reduce8_dst_lane(lane);
 
-    // ---- owner state.  Owner slot o = tid + 128 s; the K <= 64 CP angles come first (all in wave 0, slot 0).
+    // ---- owner state.  Owner slot o = (tid ^ 64) + 128 s; the K <= 64 CP angles come first, i.e. all in wave B
+    // (slot 0).  Wave A (surface gates + its half) is the critical path of every step and wave B has ~20 % slack
+    // (per-phase stamps), so everything that is not a sweep sits in wave B: the penalty of the CP angles, the loss,
+    // best-iterate tracking and the epilogue.
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
     int cs_off[PPT], g_off[PPT], pj[PPT];
     bool valid[PPT], is_cp[PPT], frz[PPT];
     penalty_table_init(smem, a, tid);
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
-        const int o = tid + TH * s;
+        const int o = (tid ^ 64) + TH * s;
         valid[s] = o < P;
         int j = 0;
         if (valid[s]) {
@@ -609,7 +612,6 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         CPF_STAMP(7)
         // ================= forward: A builds H1 from the identity, B builds W = H2^+ V
         if (wave == 0) {
-            if (a.use_reg) { pen_sum = wave_sum(pval[0]); red[0] = pen_sum; }
             st.p[0] = f2{(L::row_index(lane, 0) == col) ? 1.f : 0.f, 0.f};
             float sr[Lds::SURF_F];
 #pragma unroll
@@ -627,6 +629,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             split_fwd<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS, m, ph, sp);
             xch[0] = st.p[0];
         } else {
+            if (a.use_reg) pen_sum = wave_sum(pval[0]);        // CP angles: all owned by wave B, slot 0
             st.p[0] = vt;
             split_inv<L, PL, LL, ROT, STORE, PS, OFF>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
             xch[64] = st.p[0];
@@ -637,14 +640,14 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         // ================= loss (both waves, identical arithmetic), best tracking
         f2 w;                                         // W = H2^+ V at the cut
         if (wave == 0) w = xch[64];
-        else { w = st.p[0]; st.p[0] = xch[0]; if (a.use_reg) pen_sum = red[0]; }
+        else { w = st.p[0]; st.p[0] = xch[0]; }
         const f2 tt = cmul_conj(st.p[0], w);          // T = sum psi conj(W)
         float tr = tt.x, ti = tt.y;
         wave_sum2(tr, ti);
-        // wave A alone turns T into the loss and tracks the best iterate; wave B needs only T (for the cotangent)
-        // and, at its owner phase, A's verdict on whether this iterate is the best so far (red[1])
+        // wave B alone turns T into the loss and tracks the best iterate; wave A needs only T (for the cotangent)
+        // and, at its owner phase, B's verdict on whether this iterate is the best so far (red[1])
         bool improved = false;
-        if (wave == 0) {
+        if (wave != 0) {
             const float reg = a.use_reg ? a.r * pen_sum : 0.f;
             const float ab = sqrtf(fmaf(tr, tr, ti * ti));
             const float loss = 1.f - ab * ab * a.inv_dim2;
@@ -656,7 +659,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
 #pragma unroll
                 for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
             }
-            if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
+            if (a.hist_loss && lane == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         }
         if (a.hist_params) {
 #pragma unroll
@@ -703,7 +706,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         CPF_STAMP(4)                                  // waited for the other wave
 
         // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
-        if (wave != 0 && red[1] != 0.f) {              // best iterate so far (decided by wave A): keep the pre-update angles
+        if (wave == 0 && red[1] != 0.f) {              // best iterate so far (decided by wave B): keep the pre-update angles
 #pragma unroll
             for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
         }
@@ -729,8 +732,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     if (s_idx == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 * wave + k] = (float)stamp_sum[k];
 #endif
 
-    // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164): CP owners all sit in wave 0
-    if (wave == 0) {
+    // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164): CP owners, first and best all sit in wave B
+    if (wave != 0) {
         const int bi = (best < first) ? 1 : 0;
         float acc[3] = {0.f, 0.f, 0.f};
         if (is_cp[0]) {
@@ -742,7 +745,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
-        if (tid == 0) {
+        if (lane == 0) {
             const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
             const float l0 = first - reg0, l1 = best - reg1;
             a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
