@@ -365,14 +365,49 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
 // psi' = conj(f) H1 only and reads W_j back (Im(conj(f W) s psi) = Im(conj(W) s conj(f) psi): the scalar f moves
 // onto psi once).  Per block 4 x (4 + 3) + 13 VALU operations instead of 4 x (8 + 3) + 15, for NI + 1 more
 // ds_read_b64 / NI more ds_write_b64, prefetched one block ahead; no float32 drift from un-applying psi.
+// One block's loads: its record, the state before its diagonal unit read at the lane's own slot (for the unit's
+// gradients) and the state after each inner gate read at the slot of the lane's PARTNER on that gate's qubit, so
+// that the gate's gradient is two plain VALU operations (no DPP move, no DPP wait states).  spx[q] = the state
+// array seen from the partner lane on qubit q (spx[3] = own lane).
 template <int NI>
-struct BlkBuf { float r[16]; f2 x[NI > 0 ? NI : 1]; f2 rho; };
-template <int NI>
-__device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const f2* slots, const f2* ph) {
-    load_rec(rec, q.r);
+struct BlkBuf { float r[16]; f2 own; f2 part[NI > 0 ? NI : 1]; f2 rho; };
+template <class L>
+struct StatePtrs { const f2* p[L::NQ + 1]; };
+template <class L>
+__device__ __forceinline__ StatePtrs<L> state_ptrs(const f2* sp_lane, int lane) {
+    StatePtrs<L> r;
 #pragma unroll
-    for (int j = 0; j < NI; j++) q.x[j] = slots[64 * j];
+    for (int q = 0; q < L::NQ; q++) r.p[q] = sp_lane + ((lane ^ (1 << L::row_lane_bit(q))) - lane);
+    r.p[L::NQ] = sp_lane;
+    return r;
+}
+// FIRST = slot of the state before the block's unit; the inner gates' states follow it
+template <class L, int ROT, int UP, int DN, int NI>
+__device__ __forceinline__ void load_blk(BlkBuf<NI>& q, const float* rec, const StatePtrs<L>& sx, int first, const f2* ph) {
+    load_rec(rec, q.r);
+    q.own = sx.p[L::NQ][64 * first];
+    static_for([&](auto gg) __attribute__((always_inline)) {
+        constexpr int G = decltype(gg)::value;
+        using IG = InnerGate<ROT, G>;
+        constexpr int QP = IG::KIND == OP_RZ ? L::NQ : IG::template qubit<UP, DN>();
+        q.part[G] = sx.p[QP][64 * (first + 1 + G)];
+    }, typename make_iseq<NI>::type{});
     q.rho = *ph;
+}
+// this lane's share of a rotation's gradient from C (own lane) and psi read at the partner lane (Rz: own lane)
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float grad_c_own(const State<L>& st, f2 c, f2 pp) {
+    if constexpr (KIND == OP_RX) return fmaf(c.x, pp.y, -c.y * pp.x);
+    else if constexpr (KIND == OP_RY) return st.sg[Q] * fmaf(c.x, pp.x, c.y * pp.y);
+    else return -st.sg[Q] * fmaf(c.x, pp.y, -c.y * pp.x);
+}
+// the same sum over the wave with the roles swapped: psi at the own lane, C read at the partner lane (whose sign
+// on that qubit is the opposite one)
+template <class L, int KIND, int Q>
+__device__ __forceinline__ float grad_p_own(const State<L>& st, f2 cp, f2 p) {
+    if constexpr (KIND == OP_RX) return fmaf(cp.x, p.y, -cp.y * p.x);
+    else if constexpr (KIND == OP_RY) return -st.sg[Q] * fmaf(cp.x, p.x, cp.y * p.y);
+    else return -st.sg[Q] * fmaf(cp.x, p.y, -cp.y * p.x);
 }
 
 // ---- wave A backward: blocks n-1 .. 0 un-applied from C only.  Slot NI b + 1 + g = psi after inner gate g of
@@ -382,20 +417,22 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
                                                   float* gblk, int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
+    const StatePtrs<L> sx = state_ptrs<L>(sp, lane);
     BlkBuf<NI> qa, qb;
     float d[8];
     int b = n - 1;
-    f2 held = sp[64 * NI * n];                              // psi after the last inner gate of block n-1
     const f2 rho_n = ph[64 * n];
-    if (b & 1) load_blk(qb, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
-    else load_blk(qa, rec + 16 * b, sp + 64 * NI * b, ph + 64 * b);
     float dzu = 0.f, dzd = 0.f;
     {
         const int jt = (n - 1) % UNR;
         const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);   // psi, C after unit n (registers)
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = J % LL;
-            if (J == jt) { dzu = -st.sg[PL::v[2 * I]] * w; dzd = -st.sg[PL::v[2 * I + 1]] * w; }
+            if (J == jt) {
+                if constexpr (J & 1) load_blk<L, ROT, PL::v[2 * I], PL::v[2 * I + 1]>(qb, rec + 16 * b, sx, NI * b, ph + 64 * b);
+                else load_blk<L, ROT, PL::v[2 * I], PL::v[2 * I + 1]>(qa, rec + 16 * b, sx, NI * b, ph + 64 * b);
+                dzu = -st.sg[PL::v[2 * I]] * w; dzd = -st.sg[PL::v[2 * I + 1]] * w;
+            }
         }, typename make_iseq<UNR>::type{});
         phase_apply<L>(st.c[0], rho_n, true);
     }
@@ -403,26 +440,25 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
         constexpr int J = decltype(jj)::value, I = J % LL, IP = ((J + UNR - 1) % UNR) % LL;
         constexpr int UP = PL::v[2 * I], DN = PL::v[2 * I + 1];
         const int bn = b > 0 ? b - 1 : 0;
-        load_blk(nxt, rec + 16 * bn, sp + 64 * NI * bn, ph + 64 * bn);
+        load_blk<L, ROT, PL::v[2 * IP], PL::v[2 * IP + 1]>(nxt, rec + 16 * bn, sx, NI * bn, ph + 64 * bn);
 #pragma unroll
         for (int k = 0; k < 8; k++) d[k] = 0.f;
         static_for([&](auto gg) __attribute__((always_inline)) {
             constexpr int G = NI - 1 - decltype(gg)::value;
             using IG = InnerGate<ROT, G>;
             constexpr int Q = IG::template qubit<UP, DN>();
-            if constexpr (G == NI - 1) st.p[0] = held; else st.p[0] = cur.x[G + 1];
-            d[G] = rot_grad<L, IG::KIND, Q>(st);
+            d[G] = grad_c_own<L, IG::KIND, Q>(st, st.c[0], cur.part[G]);
             rot_apply<L, IG::KIND, Q>(st.c, cur.r[IG::CS], -cur.r[IG::CS + 1], st);
         }, typename make_iseq<NI>::type{});
-        phase_apply<L>(st.c[0], cur.rho, true);       // C now sits before unit b, where cur.x[0] was stored
-        held = cur.x[0];
-        const float w = fmaf(st.c[0].x, held.y, -st.c[0].y * held.x);
+        phase_apply<L>(st.c[0], cur.rho, true);                  // C now sits before unit b, where cur.own was stored
+        const float w = fmaf(st.c[0].x, cur.own.y, -st.c[0].y * cur.own.x);
         d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
         constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
         d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
         dzu = -st.sg[PL::v[2 * IP]] * w;
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
         reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        st.p[0] = cur.own;
         b--;
     };
     const int tail = n % UNR;
@@ -435,32 +471,33 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
             constexpr int J = UNR - 1 - decltype(jj)::value;
             if constexpr (J & 1) blk(ic<J>{}, qb, qa); else blk(ic<J>{}, qa, qb);
         }, typename make_iseq<UNR>::type{});
-    st.p[0] = held;
 }
 
-// ---- wave B backward: blocks 0 .. n-1 applied to psi' = conj(f) H1 only.  held = W at the cut on entry;
+// ---- wave B backward: blocks 0 .. n-1 applied to psi' = conj(f) H1 only.  wcut = W at the cut;
 // slot NI b + 1 + g = W after inner gate g of (local) block b.
 template <class L, class PL, int LL, int ROT, int OFF = 0>
-__device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const float* rec, int n, const f2* ph,
+__device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 wcut, const float* rec, int n, const f2* ph,
                                                   const f2* sp, float* gblk, int lane, int dst_lane) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
+    const StatePtrs<L> sx = state_ptrs<L>(sp, lane);
     BlkBuf<NI> qa, qb;
     float da[8], db[8];
     int b = 0;
-    load_blk(qa, rec, sp + 64, ph);
+    load_blk<L, ROT, PL::v[2 * (OFF % LL)], PL::v[2 * (OFF % LL) + 1]>(qa, rec, sx, 0, ph);
 #pragma unroll
     for (int k = 0; k < 8; k++) { da[k] = 0.f; db[k] = 0.f; }
     auto step = [&](auto jj) __attribute__((always_inline)) {
-        constexpr int J = decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
+        constexpr int J = decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL, IN = (J + OFF + 1) % LL;
         constexpr int UP = PL::v[2 * I], DN = PL::v[2 * I + 1];
         BlkBuf<NI>& cur = (J & 1) ? qb : qa;
         BlkBuf<NI>& nxt = (J & 1) ? qa : qb;
         float (&dcur)[8] = (J & 1) ? db : da;
         float (&dprv)[8] = (J & 1) ? da : db;
         const int bn = b + 1 < n ? b + 1 : b;
-        load_blk(nxt, rec + 16 * bn, sp + 64 * (NI * bn + 1), ph + 64 * bn);
-        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);          // W, psi' before unit b
+        load_blk<L, ROT, PL::v[2 * IN], PL::v[2 * IN + 1]>(nxt, rec + 16 * bn, sx, NI * bn, ph + 64 * bn);
+        const f2 held = b > 0 ? cur.own : wcut;                              // W before unit b (slot 0 is never written)
+        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);
         phase_apply<L>(st.p[0], cur.rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
@@ -474,17 +511,16 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 held, const f
             using IG = InnerGate<ROT, G>;
             constexpr int Q = IG::template qubit<UP, DN>();
             rot_apply<L, IG::KIND, Q>(st.p, cur.r[IG::CS], cur.r[IG::CS + 1], st);
-            st.c[0] = cur.x[G];
-            dcur[G] = rot_grad<L, IG::KIND, Q>(st);
+            dcur[G] = grad_p_own<L, IG::KIND, Q>(st, cur.part[G], st.p[0]);
         }, typename make_iseq<NI>::type{});
-        held = cur.x[NI - 1];
         b++;
     };
     for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
     static_for([&](auto jj) __attribute__((always_inline)) { if (b < n) step(jj); }, typename make_iseq<UNR>::type{});
     {
         const int jt = (n - 1) % UNR;
-        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);          // last unit: the Rz pair of block n-1
+        const f2 held = sp[64 * NI * n];                                     // W after the last inner gate of block n-1
+        const float w = fmaf(held.x, st.p[0].y, -held.y * st.p[0].x);        // last unit: the Rz pair of block n-1
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = (J + OFF) % LL;
             if (J == jt) {
