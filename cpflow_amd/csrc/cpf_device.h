@@ -77,6 +77,7 @@ struct KArgs {
     float* hist_loss;          // [S][T] or null
     float* out_grad;           // MODE_LOSS_GRAD: [S][P] or null
     float2* out_U;             // MODE_UNITARY: [S][N][N]
+    int prio;                  // two-ended kernel: raise the longer wave's issue priority (launches that leave SIMDs unsaturated)
 };
 
 // ------------------------------------------------------------------ layout

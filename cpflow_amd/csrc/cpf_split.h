@@ -567,6 +567,12 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     constexpr int MC = KC > 0 ? split_point(KC > 0 ? KC : 2, LL) : 0, OFF = 0;
 #endif
     const int m = KC > 0 ? MC : split_point(K, LL), kb = K - m;
+    // The wave with the longer instruction stream sets the pace of every step and the other one has slack: while the
+    // SIMDs are not saturated (a.prio, set by the host for S <= 8 x CUs) the longer one gets the higher issue
+    // priority (instruction counts as in split_point_any, + 90 for wave B's loss / penalty / best tracking).
+    // Same box: config 2 S = 1024 6.70 -> 6.53 ms, S = 2048 12.05 -> 11.17 ms, but S = 4096 22.7 -> 23.9 and config 3's
+    // shape at S = 4096 33.3 -> 35.3; with the priority on the SHORTER wave config 3's shape at S = 512 6.88 -> 8.18.
+    if (a.prio && (wave == 0) == (160 + 110 * m > 109 * kb + 90)) __builtin_amdgcn_s_setprio(3);
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;

@@ -455,6 +455,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     a.bias = pl->d_bias.as<float2>();
     build_pieces(pb->penalty, a.pc);
     a.pen_kind = pb->penalty.kind;
+    a.prio = 0;
     a.use_reg = (pb->use_reg && pb->entangler == CPF_ENTANGLER_CP) ? 1 : 0;
     a.r = (float)pb->r;
     a.lr = (float)pb->lr; a.b1 = b1f; a.b2 = b2f; a.eps = (float)pb->eps;
@@ -520,6 +521,7 @@ int32_t cpf_optimize_device(const cpf_plan* plan_c, int64_t S, const float* d_in
     CPF_HIP(hipSetDevice(plan->device));
     cpf::KArgs a = plan->base;
     a.mode = cpf::MODE_OPTIMIZE;
+    { const char* e = getenv("CPF_PRIO"); a.prio = e ? (e[0] == '1') : (S <= (int64_t)plan->num_cu * 8); }   // A/B: CPF_PRIO=0|1
     a.init = d_init; a.frozen = d_frozen;
     a.out_params = d_params; a.out_regloss = d_regloss; a.out_loss = d_loss; a.out_reg = d_reg;
     a.out_cz = d_cz; a.out_pass = d_pass;
