@@ -201,10 +201,11 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
     for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
 }
 
-// ---- wave A backward: blocks n-1 .. 0 un-applied from psi and C, gradients to gblk[32 b] (as cpf_layered.h)
+// ---- wave A backward: blocks n-1 .. 0 un-applied from psi and C, gradients to gblk[32 b] (as cpf_layered.h);
+// block 0's eight partials are returned in d0 (not reduced)
 template <class L, class PL, int LL, int ROT, bool STORE>
 __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, int n, const f2* ph, float* gblk,
-                                               int lane, int dst_lane) {
+                                               int lane, int dst_lane, float (&d0)[8]) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1;
     if (n <= 0) return;
     float ra[16], rb[16], d[8];
@@ -252,7 +253,11 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
         phase_apply<L>(st.p[0], rho, true);
         phase_apply<L>(st.c[0], rho, true);
-        reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        if (b > 0) reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        else {                                            // block 0: the caller reduces it with the ninth surface gradient in the spare slot
+#pragma unroll
+            for (int k = 0; k < 8; k++) d0[k] = d[k];
+        }
         b--;
     };
     const int tail = n % UNR;
@@ -414,7 +419,7 @@ __device__ __forceinline__ float grad_p_own(const State<L>& st, f2 cp, f2 p) {
 // block b, slot 0 = psi after the surface gates; on exit st.p holds that slot-0 state.
 template <class L, class PL, int LL, int ROT>
 __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec, int n, const f2* ph, const f2* sp,
-                                                  float* gblk, int lane, int dst_lane) {
+                                                  float* gblk, int lane, int dst_lane, float (&d0)[8]) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
     static_assert(NI >= 2, "stored-state sweep needs at least one inner rotation letter");
     const StatePtrs<L> sx = state_ptrs<L>(sp, lane);
@@ -457,7 +462,11 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
         d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
         dzu = -st.sg[PL::v[2 * IP]] * w;
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
-        reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        if (b > 0) reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        else {                                            // block 0: the caller reduces it with the ninth surface gradient in the spare slot
+#pragma unroll
+            for (int k = 0; k < 8; k++) d0[k] = d[k];
+        }
         st.p[0] = cur.own;
         b--;
     };
@@ -612,7 +621,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         pj[s] = j;
         is_cp[s] = valid[s] && a.pkind[j];
         frz[s] = valid[s] && frozen && frozen[j];
-        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
+        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
         else {
             const int b = (j - NS) / NB, k = (j - NS) % NB;
             cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
@@ -717,8 +726,9 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             else st.p[0] = cmul_conj(st.p[0], f2{fr, fi});      // wave B, stored states: f moves onto psi
         }
         if (wave == 0) {
-            if constexpr (PS) split_bwd_grad_ps<L, PL, LL, ROT>(st, smem + Lds::BLK_CS, m, ph, sp, gs + 32 * Lds::NBATCH, lane, dst_lane);
-            else split_bwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph, gs + 32 * Lds::NBATCH, lane, dst_lane);
+            float d0[8];
+            if constexpr (PS) split_bwd_grad_ps<L, PL, LL, ROT>(st, smem + Lds::BLK_CS, m, ph, sp, gs + 32 * Lds::NBATCH, lane, dst_lane, d0);
+            else split_bwd_grad<L, PL, LL, ROT, STORE>(st, smem + Lds::BLK_CS, m, ph, gs + 32 * Lds::NBATCH, lane, dst_lane, d0);
             float sr[Lds::SURF_F], ds[8 * Lds::NBATCH];
 #pragma unroll
             for (int i = 0; i < Lds::SURF_F / 4; i++) {
@@ -728,13 +738,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
 #pragma unroll
             for (int k = 0; k < 8 * Lds::NBATCH; k++) ds[k] = 0.f;
             surface_bwd_independent<L, NQ>(st, sr, ds);
-#pragma unroll
-            for (int bt = 0; bt < Lds::NBATCH; bt++) {
+            // nine surface gradients: eight fill one reduce-scatter batch, the ninth rides in the spare slot of
+            // block 0's batch (a block has 7 angles): one 17-instruction reduction less on the critical wave
+            static_assert(NS == 9 && NB <= 7, "surface gradient packing assumes 3 qubits and a spare slot per block");
+            {
                 float d8[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) d8[k] = ds[8 * bt + k];
-                reduce8_rows(d8, gs + 32 * bt, lane, dst_lane);
+                for (int k = 0; k < 8; k++) d8[k] = ds[k];
+                reduce8_rows(d8, gs, lane, dst_lane);
             }
+            d0[7] = ds[8];
+            reduce8_rows(d0, gs + 32 * Lds::NBATCH, lane, dst_lane);
         } else {
             if constexpr (PS)
                 split_fwd_grad_ps<L, PL, LL, ROT, OFF>(st, w, smem + Lds::BLK_CS + 16 * m, kb, ph, sp,
