@@ -32,10 +32,10 @@ __host__ __device__ constexpr int split_point(int K, int LL) {
 __host__ __device__ constexpr bool split_supported(int K, int LL) { return K >= 2 * LL && K >= 2 && K <= 64; }
 // With K a compile-time constant the cut need not fall on a layer boundary (wave B's pair indices carry the offset
 // m mod LL).  Instruction counts of the packed stored-state sweeps: wave A = 160 (surface gates, both directions)
-// + 110 per block, wave B = 109 per block  ->  m = (109 K - 160) / 219 rounded: 5 of 12, 7 of 16.  Not the default:
-// see split_body.
+// + 110 per block, wave B = 109 per block + 90 (loss, penalty, best tracking)  ->  m = (109 K - 70) / 219 rounded:
+// 6 of 12 (the layer cut), 8 of 16.
 __host__ __device__ constexpr int split_point_any(int K) {
-    int m = (2 * (109 * K - 160) + 219) / (2 * 219);
+    int m = (2 * (109 * K - 70) + 219) / (2 * 219);
     if (m < 1) m = 1;
     if (m > K - 1) m = K - 1;
     return m;

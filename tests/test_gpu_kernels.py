@@ -359,3 +359,18 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
     eng = _engine([[0, 1], [1, 2]], 66, ccz, 'xyz', num_gd_iterations=3)
     eng.optimize(eng.initial_angles(0, 8))
     assert eng.last_variant().startswith('layered/')
+
+
+def test_issue_priority_does_not_change_results(monkeypatch):
+    """The two-ended kernel raises the issue priority of its longer wave when the launch leaves SIMDs unsaturated
+    (cpf_split.h): a scheduling hint only - outputs are bit-identical with it on and off."""
+    ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
+    res = {}
+    for prio in ('0', '1'):
+        monkeypatch.setenv('CPF_PRIO', prio)
+        eng = _engine([[0, 1], [1, 2]], 12, ccz, 'xyz', num_gd_iterations=300)
+        out = eng.optimize(eng.initial_angles(3, 200))
+        assert eng.last_variant().startswith('split/')
+        res[prio] = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+    for k in res['0']:
+        assert np.array_equal(res['0'][k], res['1'][k]), k
