@@ -26,25 +26,46 @@ __device__ __forceinline__ int reduce8_dst_lane(int lane) {
     const int k = 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);     // value index this lane ends up holding
     return k * 4 + (lane >> 4);
 }
+// SEVEN: d[7] is unused (a block has 7 angles).  The instruction that would add it is dropped; lanes of banks 1, 3
+// then carry an undefined e3, which the later stages only ever combine with other "value 7" lanes (the
+// reduce-scatter never mixes value indices), so it ends in dst[28..31] of the batch, which no owner reads.
+template <bool SEVEN = false>
 __device__ __forceinline__ void reduce8_rows(const float (&d)[8], float* dst, int lane, int dst_lane) {
     float e0, e1, e2, e3, f0, f1;
     // s_nop 1: the operands may come straight from a VALU write (2 wait states before a DPP read); inside the
     // block every DPP read is >= 3 instructions behind the write it depends on.
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %5, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
-        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(f0), "=&v"(f1)
-        : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+    if constexpr (SEVEN) {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
+            : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(f0), "=&v"(f1)
+            : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
+            : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(f0), "=&v"(f1)
+            : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+    }
     const bool b0 = lane & 1;
     const float keep = b0 ? f1 : f0, give = b0 ? f0 : f1;
     float r = keep + dppz<0xB1>(give);

@@ -197,6 +197,7 @@ struct State {
     float sg[L::NLR > 0 ? L::NLR : 1];   // +1 if this lane's bit of lane-row-qubit i is set, else -1
     f2 sgp[L::NLR > 0 ? L::NLR : 1];     // (1, sg): turns a record's (cos, sin) into cos + i sigma sin in one packed multiply
     bool lb[L::NLR > 0 ? L::NLR : 1];
+    float cpm2[3];                       // 3-qubit kernels: the CP gradient's lane factor for the pairs (0,1), (0,2), (1,2): -2 or 0
 };
 
 // ---- rotations: forward / inverse application to one matrix

@@ -229,6 +229,9 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     State<L> st;
 #pragma unroll
     for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; st.sgp[i] = f2{1.f, st.sg[i]}; }
+    if constexpr (L::NQ == 3 && L::NLR == 3) {                // one element per lane: -2 on the |11> rows of each qubit pair, else 0
+        st.cpm2[0] = (st.lb[0] && st.lb[1]) ? -2.f : 0.f; st.cpm2[1] = (st.lb[0] && st.lb[2]) ? -2.f : 0.f; st.cpm2[2] = (st.lb[1] && st.lb[2]) ? -2.f : 0.f;
+    }
     const int col = L::col_index(lane, wave);
     // the target stays in registers for small tiles; with 16+ elements per thread it is re-read from
     // L2 once per step (2 x 8 E bytes per thread per ~1e5 cycles) to keep the kernel out of scratch
@@ -466,7 +469,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                     const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);     // shared by CP(b), Rz(up), Rz(dn) of block b-1
                     constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
                     constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
-                    d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+                    d[NB - 1] = st.cpm2[Q0 + Q1 - 1] * w;
                     dzu = -st.sg[PL::v[2 * IP]] * w;
                     dzd = -st.sg[PL::v[2 * IP + 1]] * w;
                     phase_apply<L>(st.p[0], rho, true);
@@ -474,7 +477,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
                 } else {
                     lay_block_bwd<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, d);
                 }
-                reduce8_rows(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
+                reduce8_rows<true>(d, gslab + 32 * Lds::NBATCH + 32 * b, lane, dst_lane);
                 gate_fence<L>();
                 b--;
             };

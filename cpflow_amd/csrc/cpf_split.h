@@ -248,12 +248,12 @@ __device__ __forceinline__ void split_bwd_grad(State<L>& st, const float* rec, i
         const float w = fmaf(st.c[0].x, st.p[0].y, -st.c[0].y * st.p[0].x);
         constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
         constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
-        d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        d[NB - 1] = st.cpm2[Q0 + Q1 - 1] * w;
         dzu = -st.sg[PL::v[2 * IP]] * w;
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
         phase_apply<L>(st.p[0], rho, true);
         phase_apply<L>(st.c[0], rho, true);
-        if (b > 0) reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        if (b > 0) reduce8_rows<true>(d, gblk + 32 * b, lane, dst_lane);
         else {                                            // block 0: the caller reduces it with the ninth surface gradient in the spare slot
 #pragma unroll
             for (int k = 0; k < 8; k++) d0[k] = d[k];
@@ -334,12 +334,12 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
         phase_apply<L>(st.c[0], rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
-        if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
+        if (b > 0) reduce8_rows<true>(dprv, gblk + 32 * (b - 1), lane, dst_lane);
         constexpr int Q0 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I] : PL::v[2 * I + 1];
         constexpr int Q1 = PL::v[2 * I] < PL::v[2 * I + 1] ? PL::v[2 * I + 1] : PL::v[2 * I];
 #pragma unroll
         for (int k = 0; k < 8; k++) dcur[k] = 0.f;
-        dcur[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        dcur[NB - 1] = st.cpm2[Q0 + Q1 - 1] * w;
         lay_block_fwd_grad_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, dcur);
         if constexpr (!STORE) {
 #pragma unroll
@@ -358,7 +358,7 @@ __device__ __forceinline__ void split_fwd_grad(State<L>& st, const float* rec, i
                 float (&dl)[8] = (J & 1) ? db : da;
                 dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
                 dl[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * I + 1]] * w;
-                reduce8_rows(dl, gblk + 32 * (n - 1), lane, dst_lane);
+                reduce8_rows<true>(dl, gblk + 32 * (n - 1), lane, dst_lane);
             }
         }, typename make_iseq<UNR>::type{});
     }
@@ -459,10 +459,10 @@ __device__ __forceinline__ void split_bwd_grad_ps(State<L>& st, const float* rec
         const float w = fmaf(st.c[0].x, cur.own.y, -st.c[0].y * cur.own.x);
         d[2 * (NR - 1)] = dzu; d[2 * (NR - 1) + 1] = dzd;
         constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
-        d[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        d[NB - 1] = st.cpm2[Q0 + Q1 - 1] * w;
         dzu = -st.sg[PL::v[2 * IP]] * w;
         dzd = -st.sg[PL::v[2 * IP + 1]] * w;
-        if (b > 0) reduce8_rows(d, gblk + 32 * b, lane, dst_lane);
+        if (b > 0) reduce8_rows<true>(d, gblk + 32 * b, lane, dst_lane);
         else {                                            // block 0: the caller reduces it with the ninth surface gradient in the spare slot
 #pragma unroll
             for (int k = 0; k < 8; k++) d0[k] = d[k];
@@ -510,11 +510,11 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 wcut, const f
         phase_apply<L>(st.p[0], cur.rho, false);
         dprv[2 * (NR - 1)] = -st.sg[PL::v[2 * IP]] * w;
         dprv[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * IP + 1]] * w;
-        if (b > 0) reduce8_rows(dprv, gblk + 32 * (b - 1), lane, dst_lane);
+        if (b > 0) reduce8_rows<true>(dprv, gblk + 32 * (b - 1), lane, dst_lane);
         constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
 #pragma unroll
         for (int k = 0; k < 8; k++) dcur[k] = 0.f;
-        dcur[NB - 1] = cp_lane_pred<L, Q0, Q1>(st) ? -2.f * w : 0.f;
+        dcur[NB - 1] = st.cpm2[Q0 + Q1 - 1] * w;
         static_for([&](auto gg) __attribute__((always_inline)) {
             constexpr int G = decltype(gg)::value;
             using IG = InnerGate<ROT, G>;
@@ -536,7 +536,7 @@ __device__ __forceinline__ void split_fwd_grad_ps(State<L>& st, f2 wcut, const f
                 float (&dl)[8] = (J & 1) ? db : da;
                 dl[2 * (NR - 1)] = -st.sg[PL::v[2 * I]] * w;
                 dl[2 * (NR - 1) + 1] = -st.sg[PL::v[2 * I + 1]] * w;
-                reduce8_rows(dl, gblk + 32 * (n - 1), lane, dst_lane);
+                reduce8_rows<true>(dl, gblk + 32 * (n - 1), lane, dst_lane);
             }
         }, typename make_iseq<UNR>::type{});
     }
@@ -595,6 +595,9 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     State<L> st;
 #pragma unroll
     for (int i = 0; i < L::NLR; i++) { st.lb[i] = (lane >> L::row_lane_bit(i)) & 1; st.sg[i] = st.lb[i] ? 1.f : -1.f; st.sgp[i] = f2{1.f, st.sg[i]}; }
+    if constexpr (L::NQ == 3 && L::NLR == 3) {                // one element per lane: -2 on the |11> rows of each qubit pair, else 0
+        st.cpm2[0] = (st.lb[0] && st.lb[1]) ? -2.f : 0.f; st.cpm2[1] = (st.lb[0] && st.lb[2]) ? -2.f : 0.f; st.cpm2[2] = (st.lb[1] && st.lb[2]) ? -2.f : 0.f;
+    }
     const int col = L::col_index(lane, 0);
     const float2 vt_ = a.target[L::row_index(lane, 0) * L::D + col];
     const f2 vt = {vt_.x, vt_.y};
