@@ -64,6 +64,7 @@ struct cpf_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int num_cu = 256;
+    int64_t lds_per_cu = 160 * 1024;   // bytes of LDS per CU (device property; 160 KiB on gfx950)
     ~cpf_plan() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -130,13 +131,14 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
 // (chain_layer(3), connected_layer(3); topology.py:7-12), 'xyz' / 'xz', optimiser state for <= 128 / 256 angles.
 // Stored phases cost 512 (K + 1) bytes of LDS per sample: use them while that does not cut the number of
 // resident workgroups the launch needs (S / CUs, at most ~5 per SIMD by registers).
-bool phases_fit(int num_cu, int64_t S, size_t lds_bytes_with_phases) {
+bool phases_fit(const cpf_plan* plan, int64_t S, size_t lds_bytes_with_phases) {
+    const int num_cu = plan->num_cu;
     { const char* e = getenv("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // same-box A/B (ms, store vs rebuild): config 2 S=1024 10.06/10.53, S=4096 24.45/26.15, S=16384 96.1/93.5;
     // config 3 S=1024 12.89/13.75, S=4096 38.5/35.4 -> store only while LDS still admits the workgroups the launch
     // wants per CU (registers cap that at ~20)
     const int64_t want = std::min<int64_t>((S + num_cu - 1) / num_cu, 20);
-    return (int64_t)(160 * 1024 / lds_bytes_with_phases) >= want;
+    return (int64_t)(plan->lds_per_cu / (int64_t)lds_bytes_with_phases) >= want;
 }
 // Two waves per sample (cpf_split.h) while the one-wave kernel would leave SIMDs with a single wave: the step is
 // then one exposed dependent chain, and cutting it in two is worth more than the second wave's issue slots.
@@ -150,12 +152,13 @@ bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int ro
 bool kspec_enabled() { const char* e = getenv("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
 // Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
 // them while LDS still admits the workgroups the launch wants on a CU.
-bool states_fit(int num_cu, int64_t S, int rot_code, size_t lds_bytes_with_states) {
+bool states_fit(const cpf_plan* plan, int64_t S, int rot_code, size_t lds_bytes_with_states) {
+    const int num_cu = plan->num_cu;
     if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > 64 * 1024) return false;
     { const char* e = getenv("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // only while every workgroup of the launch is resident at once (same box, config 2 shape: S = 1024 6.95 vs 7.15 ms
     // with / without states, S = 2048 17.5 vs 15.1, S = 4096 32.1 vs 22.8)
-    return (int64_t)(160 * 1024 / lds_bytes_with_states) >= (S + num_cu - 1) / num_cu;
+    return (int64_t)(plan->lds_per_cu / (int64_t)lds_bytes_with_states) >= (S + num_cu - 1) / num_cu;
 }
 // K-specialised two-ended kernels exist ahead of time for the BASELINE 3-qubit configurations
 // (chain_layer(3) with 12 blocks, connected_layer(3) with 16; 'xyz'); KC = 0: K is read from the plan.
@@ -164,7 +167,7 @@ int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStre
     const size_t lds2 = (size_t)cpf::SplitLds::total(K, 2, cpf::inner_gates<ROT>()) * sizeof(float);
     const char* tag = KC ? " K" : "";
     if constexpr (cpf::rot_nr(ROT) >= 2) {
-        if (states_fit(plan->num_cu, S, ROT, lds2)) {
+        if (states_fit(plan, S, ROT, lds2)) {
             hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT, 2 + 4 * KC, UD...>), dim3((unsigned)S), dim3(128), lds2, stream, a);
             CPF_HIP(hipGetLastError());
             plan->variant = std::string("split/aot waves=2 states") + tag;
@@ -192,7 +195,7 @@ int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t 
     const bool merge = cpf::layered_merge(3, 0, ROT);
     const size_t lds1 = (size_t)cpf::LayeredLds<3>::total(K, 1, merge) * sizeof(float);
     const size_t lds0 = (size_t)cpf::LayeredLds<3>::total(K, 1, false) * sizeof(float);
-    if (merge && lds1 <= 64 * 1024 && phases_fit(plan->num_cu, S, lds1))
+    if (merge && lds1 <= 64 * 1024 && phases_fit(plan, S, lds1))
         hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, 1, UD...>), dim3((unsigned)S), dim3(64), lds1, stream, a);
     else
         hipLaunchKernelGGL((cpf::k_cp_layered<3, 0, ROT, PPT, 0, UD...>), dim3((unsigned)S), dim3(64), lds0, stream, a);
@@ -268,7 +271,7 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = (a.P + 127) / 128;
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
-        const int smstore = (states_fit(plan->num_cu, S, rot_code, slds2) ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
+        const int smstore = (states_fit(plan, S, rot_code, slds2) ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
         const size_t slds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
         std::string serr;
         hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, smstore, plan->layer_ud, &serr, true) : nullptr;
@@ -284,7 +287,7 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
     }
     if (plan->NQ == 3 && cpf::layered_merge(3, lw, rot_code)) {
         const size_t with = (size_t)cpf::LayeredLds<3>::total(plan->K, 1, true) * sizeof(float);
-        mstore = (with <= 64 * 1024 && phases_fit(plan->num_cu, S, with)) ? 1 : 0;
+        mstore = (with <= 64 * 1024 && phases_fit(plan, S, with)) ? 1 : 0;
     }
     switch (plan->NQ) {
         case 3: lds = cpf::LayeredLds<3>::total(plan->K, 1 << lw, mstore != 0); break;
@@ -445,6 +448,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
         return fail((int)e, "plan upload failed: %s", hipGetErrorString(e));
     }
     pl->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) pl->lds_per_cu = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
 
     cpf::KArgs& a = pl->base;
     a.prog = pl->d_prog.as<int4>(); a.G = pl->G; a.P = P; a.T = pl->T; a.mode = cpf::MODE_OPTIMIZE;
