@@ -6,16 +6,23 @@ initial angles from the seed on the device, run num_gd_iterations Adam iteration
 sample (one persistent HIP kernel), evaluate CZ counts / entry-loss flags, and (N > 1)
 all-gather the per-sample summaries.  value = (samples x iterations x steps) / wall time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): CCZ target, 3 qubits, chain layer [[0,1],[1,2]],
+Started WITHOUT torchrun and with --gpus N > 1, this process only launches N fresh worker
+processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child) before
+any GPU call of its own, and relays rank 0's JSON line.
+
+Default workload (BASELINE.json configs[1]): CCZ target, 3 qubits, chain layer [[0,1],[1,2]],
 num_cp_gates=12, num_samples=1024 per GPU, 2000 iterations, lr 0.1, r 0.00055, seed 0.
-Weak scaling: every rank runs 1024 samples (global sample rows rank*1024 ...).
+Weak scaling: every rank runs the configuration's per-GPU sample count (global sample rows
+rank*count ...).  --config selects another BASELINE configuration (cpflow_amd/workloads.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,11 +31,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector = f32 MFMA dense peak
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed v_pk_fma_f32 issue) = f32 MFMA dense peak
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(layer, K, target, rot, T, r, budget_s=12.0):
+def launch_ranks(n):
+    """--gpus N without torchrun: start N workers (this file again) and relay rank 0's stdout.
+    Nothing in this process has touched the GPU (torch is not even imported yet)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
     """Time the CPU restatement (oracle/, a C port of the JAX path, OpenMP over samples) on the
     host cores, on a bounded sample of the same workload.  Reported, never shipped."""
     import oracle
@@ -38,22 +66,41 @@ def cpu_baseline(layer, K, target, rot, T, r, budget_s=12.0):
         lib_path = os.path.join(ROOT, 'oracle', '_build', 'libcpf_oracle_native.so')
     except Exception:
         pass
-    orc = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=T, lib_path=lib_path)
-    cores = int(orc.lib.cpfo_max_threads())
-    init = orc.initial_angles(0, cores)
+    cal = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=min(T, 20), lib_path=lib_path)
+    cores = int(cal.lib.cpfo_max_threads())
+    init = cal.initial_angles(0, cores)
     t0 = time.time()
-    orc.run(init, np.float32, nthreads=cores)          # calibration: one sample per core
-    dt = max(time.time() - t0, 1e-3)
-    # ~budget_s seconds of work: whole multiples of the core count, rows of the same seed-0 angle matrix
-    S = int(min(max(cores, cores * int(budget_s / dt)), 65536))
+    cal.run(init, np.float32, nthreads=cores)          # calibration: one sample per core, 20 iterations
+    per_step = max(time.time() - t0, 1e-4) / min(T, 20)
+    # ~budget_s seconds of work: all T iterations on whole multiples of the core count when one batch of `cores` samples
+    # fits the budget, otherwise `cores` samples over as many iterations as fit (rows of the same seed-0 angle matrix)
+    reps = int(budget_s / (per_step * T))
+    S, T_run = (int(min(cores * reps, 65536)), T) if reps >= 1 else (cores, max(20, int(budget_s / per_step)))
+    orc = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=T_run, lib_path=lib_path)
     init = orc.initial_angles(0, S)
     t0 = time.time()
     orc.run(init, np.float32, nthreads=cores)
     dt = time.time() - t0
-    return {'value': S * T / dt, 'unit': 'sample-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{S} samples (seed-0 initial angles) x {T} iterations of the same 3q CCZ workload, float32 C '
-                      f'restatement of the JAX path (oracle/cpf_oracle.c, OpenMP, '
+    return {'value': S * T_run / dt, 'unit': 'sample-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{S} samples (seed-0 initial angles) x {T_run} iterations of the same workload ({wl.name}: {wl.title}), '
+                      f'float32 C restatement of the JAX path (oracle/cpf_oracle.c, OpenMP, '
                       f'{"-march=native" if lib_path else "portable -O3"}), {dt:.1f} s'}
+
+
+def stored_traffic(config, samples_per_gpu):
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this
+    configuration (profiles/r*_<config>_pmc_summary.json; counters need their own profiler passes, so they cannot be
+    read inside this run).  Returns (bytes or None, file name or None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if d.get('config', 'cfg2') == config and d.get('samples', 1024) == samples_per_gpu and d.get('traffic_bytes_per_launch'):
+            return d['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -61,13 +108,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--samples-per-gpu', type=int, default=1024)
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
+                    help='BASELINE.json configuration (default: configs[1], the one the metric is quoted on)')
+    ap.add_argument('--samples-per-gpu', type=int, default=None, help="override the configuration's per-GPU sample count")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
-    from cpflow_amd import distributed
+    from cpflow_amd import distributed, workloads
     from cpflow_amd.engine import TemplateEngine
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -75,21 +127,25 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         # CPF_DIST_BACKEND=gloo + CPF_ONE_DEVICE=1 emulate N ranks on a single GPU (contract smoke test only)
-        if os.environ.get('CPF_ONE_DEVICE') == '1':
+        one_device = os.environ.get('CPF_ONE_DEVICE') == '1'
+        if one_device:
             local_rank = 0
+        elif torch.cuda.device_count() < world:
+            sys.exit(f'[bench] {world} ranks but {torch.cuda.device_count()} visible GPU(s); on a 1-GPU box the N-rank '
+                     f'path can be rehearsed with CPF_ONE_DEVICE=1 CPF_DIST_BACKEND=gloo')
         torch.cuda.set_device(local_rank)
-        backend = os.environ.get('CPF_DIST_BACKEND', 'nccl')
+        backend = os.environ.get('CPF_DIST_BACKEND', 'gloo' if one_device else 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
-    n_gpus = world if world > 1 else 1
+    n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {n_gpus} rank(s)', file=sys.stderr)
 
-    layer, K, rot, T, r, seed = [[0, 1], [1, 2]], 12, 'xyz', 2000, 0.00055, 0
-    target = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(np.complex128)       # CCZ
-    S_local = args.samples_per_gpu
+    wl = workloads.CONFIGS[args.config]
+    layer, K, rot, T, r, seed, target = wl.layer, wl.num_cp_gates, wl.rotation_gates, wl.num_gd_iterations, wl.r, wl.seed, wl.target
+    S_local = args.samples_per_gpu or wl.samples_per_gpu
     S_total = S_local * n_gpus
     eng = TemplateEngine(layer, K, target, rot, r=r, num_gd_iterations=T, device=local_rank if world > 1 else None)
     first, count = distributed.shard_range(S_total, rank, n_gpus)
@@ -117,7 +173,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k_ms, _all = eng.mean_kernel_ms()   # average launch duration over the timed region
+    k_ms, k_all = eng.mean_kernel_ms()  # average launch duration over the timed region
     eng.event_log = None
     out, summary = step()
     fence()
@@ -129,30 +185,27 @@ def main():
 
     if rank == 0:
         value = S_total * T * args.steps / elapsed
-        flops = eng.flops_per_sample_step                      # 3 N^2 (32 K + 16 n) + 20 P = 84,804
+        flops = eng.flops_per_sample_step                      # 3 N^2 (32 K + 16 n) + 20 P (84,804 at config 2)
         achieved_tf = flops * S_local * T / (k_ms * 1e-3) / 1e12
-        P = eng.num_angles
-        alg_bytes = S_local * (8 * P + 28) + 8 * 8 * 8         # persistent model: theta0 in, best theta + scalars out
-        traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        try:
-            import glob
-            newest = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))[-1]
-            with open(newest) as f:
-                traffic = json.load(f)['traffic_bytes_per_launch'] if S_local == 1024 else None
-        except Exception:
-            pass
+        P, N = eng.num_angles, 1 << wl.num_qubits
+        alg_bytes = S_local * (8 * P + 28) + 8 * N * N         # persistent model: theta0 in, best theta + scalars out
+        traffic, traffic_src = stored_traffic(args.config, S_local)
         line = {
-            'metric': 'optimizer steps/sec x num_samples (sample-steps/s), 3q CCZ synth',
+            'metric': 'optimizer steps/sec x num_samples (sample-steps/s), 3q CCZ synth' if args.config == 'cfg2'
+                      else f'optimizer steps/sec x num_samples (sample-steps/s), BASELINE {args.config}',
             'value': value, 'unit': 'sample-steps/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'CCZ 3q, chain [[0,1],[1,2]], num_cp_gates={K}, num_samples={S_local}/GPU '
-                                   f'({S_total} total), num_gd_iterations={T}, lr=0.1, r={r}, seed={seed}, xyz',
+            'config': {'workload': f'{args.config}: {wl.title}, num_cp_gates={K}, num_samples={S_local}/GPU '
+                                   f'({S_total} total), num_gd_iterations={T}, lr=0.1, r={r}, seed={seed}, {rot}',
                        'parallelism': f'sample-sharded x{n_gpus}', 'passed_entry_loss': int(summary['passed'].sum())},
-            'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / FP32_PEAK_TFLOPS, 'traffic': traffic,
-                         'note': 'fp32 vector ALU work (no MFMA used); peak = f32 vector = f32 MFMA dense peak; '
-                                 f'kernel {k_ms:.3f} ms per launch (HIP events), {flops:.0f} flop/sample-step',
+            'roofline': {'bound': 'valu', 'achieved': achieved_tf, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved_tf / FP32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'note': 'FP32 vector-ALU issue bound (no MFMA, no HBM traffic inside the run); peak = packed-FMA '
+                                 f'vector peak; kernel {k_ms:.3f} ms per launch (mean of {len(k_all)} timed launches, HIP '
+                                 f'events on the launch stream; median {sorted(k_all)[len(k_all) // 2]:.3f}), '
+                                 f'{flops:.0f} flop/sample-step; traffic = HBM bytes per launch from the stored rocprofv3 '
+                                 '--pmc passes named in traffic_source (not measured in this run)',
                          'kernel': eng.last_variant()},
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes,
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,
@@ -160,7 +213,7 @@ def main():
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
-                line['cpu_baseline'] = cpu_baseline(layer, K, target, rot, T, r)
+                line['cpu_baseline'] = cpu_baseline(wl, layer, K, target, rot, T, r)
                 line['speedup_vs_cpu_port'] = value / line['cpu_baseline']['value']
             except Exception as e:      # the baseline is reported, never required
                 line['cpu_baseline'] = {'value': None, 'unit': 'sample-steps/s', 'cores': 0, 'kind': 'port',

@@ -48,9 +48,14 @@ def gather_samples(local, num_samples, group=None, force_collective=False):
     for name in names:
         t = local[name]
         assert t.shape[0] == count, (name, t.shape, count)
-        flat = t.reshape(count, -1).to(torch.float32)
+        # explicit width: reshape(0, -1) is ambiguous on a rank whose shard is empty (e.g. 10 samples on 8 ranks),
+        # and such a rank must still enter the collective
+        width = 1
+        for d in t.shape[1:]:
+            width *= int(d)
+        flat = t.reshape(count, width).to(torch.float32)
         cols.append(flat)
-        widths.append(flat.shape[1])
+        widths.append(width)
     slab = torch.cat(cols, dim=1) if cols else torch.empty(count, 0)
     pad = torch.zeros(cap, slab.shape[1], dtype=torch.float32, device=slab.device)
     pad[:count] = slab

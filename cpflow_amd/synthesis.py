@@ -375,9 +375,18 @@ class Synthesize:
                            learning_rate=float(options.learning_rate_at_verification),
                            num_gd_iterations=int(options.num_gd_iterations_at_verification),
                            threshold_cp=float(options.threshold_cp), entry_loss=float(options.target_loss))
-        out = eng.optimize(init, frozen=frozen)
-        losses = out['regloss'].cpu().numpy()
-        params = out['params'].cpu().numpy()
+        # the batch is sharded over the ranks like the raw stage (contiguous blocks), one gather afterwards
+        import torch
+        rank, size = distributed.world()
+        first, count = distributed.shard_range(len(prospective), rank, size)
+        if count:
+            out = eng.optimize(init[first:first + count], frozen=frozen[first:first + count])
+            fields = {'regloss': out['regloss'], 'params': out['params']}
+        else:
+            fields = {'regloss': torch.zeros(0, 2, device=eng.device), 'params': torch.zeros(0, 2, P, device=eng.device)}
+        fields = distributed.gather_samples(fields, len(prospective))
+        losses = fields['regloss'].cpu().numpy()
+        params = fields['params'].cpu().numpy()
         verified = []
         for k, (num_cz, _res) in enumerate(prospective):
             best_i = int(np.argmin(losses[k]))

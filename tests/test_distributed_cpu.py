@@ -39,7 +39,9 @@ def _worker(rank, size, port, S, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('size,S', [(2, 10), (2, 7), (3, 8)])
+# (3, 2), (4, 5): some ranks own no sample (shard_range hands out empty shards whenever ceil(S/R)(R-1) >= S,
+# e.g. the README's num_samples=10 on 8 ranks); they must still take part in the collective
+@pytest.mark.parametrize('size,S', [(2, 10), (2, 7), (3, 8), (3, 2), (4, 5)])
 def test_gather_equals_single_rank(size, S):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""GPU-side diagnostics in one CLI (none of this is a test or a product path).  Run from anywhere:
+
+    python tools/gpu.py perf [cfg2 cfg3 cfg4 cfg5 n5 ...]      kernel time (HIP events) of the optimise launch; env T, FIRST=1
+    python tools/gpu.py one <cfg> [S] [T]                      one warm-up + one launch (for rocprofv3 passes)
+    python tools/gpu.py knobs <cfg> <S> "K=V,..." "K=V,..."    same-process A/B over the library's environment knobs
+    python tools/gpu.py ablib libA.so libB.so [cfg]            same-box A/B of two builds (alternating processes, CPF_LIB)
+    python tools/gpu.py agree <KNOB> [cfg2|cfg3]               two settings of a knob: agreement on short runs + timing over S
+    python tools/gpu.py fuzz [n_cases] [seed]                  random layers / block counts / rotation strings vs the f64 oracle
+    python tools/gpu.py fix4                                   4-qubit golden fixture: pass set of each kernel variant
+    python tools/gpu.py stamps                                 per-phase cycle shares (library built with -DCPF_STAMPS)
+    python tools/gpu.py static-e2e                             wall time of Synthesize.static() end to end
+    python tools/gpu.py host-api                               end-to-end timing of the host-pointer entry cpf_run_static
+"""
+import itertools
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rand_u(n, seed):
+    rng = np.random.default_rng(seed) if not isinstance(seed, np.random.Generator) else seed
+    a = rng.normal(size=(2 ** n, 2 ** n)) + 1j * rng.normal(size=(2 ** n, 2 ** n))
+    q, r = np.linalg.qr(a)
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def configs():
+    """name -> (layer, K, target, sample counts); cfg2..cfg5 are BASELINE.json's (cpflow_amd/workloads.py)."""
+    from cpflow_amd import workloads as w
+    c = {k: (v.layer, v.num_cp_gates, v.target, [v.samples_per_gpu]) for k, v in w.CONFIGS.items()}
+    c['cfg2'] = c['cfg2'][:3] + ([1024, 2048, 4096, 16384],)
+    c['cfg3'] = c['cfg3'][:3] + ([512, 4096],)
+    c['n5'] = ([[0, 1], [1, 2], [2, 3], [3, 4]], 36, rand_u(5, 0), [1000])
+    c['n4star'] = ([[0, 1], [0, 2], [0, 3]], 23, rand_u(4, 1), [500])
+    return c
+
+
+def engine(cfg, T=None, **kw):
+    from cpflow_amd.engine import TemplateEngine
+    layer, K, tgt, Ss = configs()[cfg]
+    return TemplateEngine(layer, K, tgt, kw.pop('rot', 'xyz'), num_gd_iterations=int(os.environ.get('T', '2000')) if T is None else T, **kw), Ss
+
+
+def timed(eng, init, reps=3):
+    import torch
+    out = eng.optimize(init)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        out = eng.optimize(init)
+        ms.append(eng.last_kernel_ms())
+    return out, min(ms)
+
+
+def cmd_perf(args):
+    for name in (args or ['cfg2']):
+        eng, Ss = engine(name)
+        T = eng.num_gd_iterations
+        for S in (Ss[:1] if os.environ.get('FIRST') else Ss):
+            out, ms = timed(eng, eng.initial_angles(0, S))
+            ok = out['passed']
+            print(f'{name} S={S} T={T} kernel {ms:.2f} ms  {S * T / ms * 1e3:.3e} sample-steps/s  '
+                  f'{eng.flops_per_sample_step * S * T / ms * 1e3 / 1e12:.2f} TFLOP/s  [{eng.last_variant()}] passed {int(ok.sum())} '
+                  f'minCZ {int(out["cz"][ok].min()) if ok.any() else -1}', flush=True)
+
+
+def cmd_one(args):
+    import torch
+    cfg = args[0] if args else 'cfg2'
+    eng, Ss = engine(cfg, T=int(args[2]) if len(args) > 2 and args[2] else None)
+    S = int(args[1]) if len(args) > 1 and args[1] else Ss[0]
+    init = eng.initial_angles(0, S)
+    for _ in range(2):
+        eng.optimize(init)
+    torch.cuda.synchronize()
+    print('kernel ms', eng.last_kernel_ms(), 'cfg', cfg, 'S', S, 'T', eng.num_gd_iterations, 'P', eng.num_angles, '[' + eng.last_variant() + ']')
+
+
+def cmd_knobs(args):
+    import torch
+    cfg, S, combos = args[0], int(args[1]), args[2:]
+    eng, _ = engine(cfg)
+    T = eng.num_gd_iterations
+    init = eng.initial_angles(0, S)
+    res, var, stats = {c: [] for c in combos}, {}, {}
+    for _ in range(5):
+        for c in combos:
+            for kv in c.split(','):
+                k, v = kv.split('=')
+                os.environ[k] = v
+            out = eng.optimize(init)
+            torch.cuda.synchronize()
+            res[c].append(eng.last_kernel_ms())
+            var[c] = eng.last_variant()
+            stats[c] = (int(out['passed'].sum()), int(out['cz'][out['passed']].min()) if out['passed'].any() else -1)
+    for c in combos:
+        print(f'{cfg} S={S} {c:40s} min {min(res[c]):.3f} ms  {S * T / min(res[c]) * 1e3:.3e}/s  [{var[c]}] passed/minCZ {stats[c]}', flush=True)
+
+
+def cmd_ablib(args):
+    libs, cfg = args[:2], (args[2] if len(args) > 2 else 'cfg2')
+    res = {lib: [] for lib in libs}
+    for _ in range(3):
+        for lib in libs:
+            env = dict(os.environ, CPF_LIB=os.path.abspath(lib), FIRST='1')
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), 'perf', cfg], env=env, capture_output=True, text=True).stdout
+            line = [x for x in out.splitlines() if x.startswith(cfg)][0]
+            res[lib].append(float(line.split('kernel')[1].split('ms')[0]))
+    for lib in libs:
+        print(os.path.basename(lib), cfg, 'S=first', 'min %.2f ms' % min(res[lib]), res[lib])
+
+
+def cmd_agree(args):
+    """e.g. agree CPF_SPLIT cfg2 (two-ended vs one-wave), agree CPF_PSTORE cfg3 (stored states vs un-applying)."""
+    import torch
+    knob, cfg = args[0], (args[1] if len(args) > 1 else 'cfg2')
+
+    def run(v, S, T, rot='xyz'):
+        os.environ[knob] = str(v)
+        eng, _ = engine(cfg, T=T, rot=rot)
+        out, ms = timed(eng, eng.initial_angles(0, S), reps=3 if T >= 1000 else 1)
+        return {k: x.cpu().numpy() for k, x in out.items() if torch.is_tensor(x)}, ms, eng.last_variant()
+    for T in (0, 1, 2, 10, 50):
+        a, _, va = run(1, 64, T)
+        b, _, vb = run(0, 64, T)
+        d = {k: float(np.max(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)))) for k in ('regloss', 'loss', 'reg', 'params')}
+        print(f'T={T:3d} [{va}] vs [{vb}] max|d|', {k: f'{v:.2e}' for k, v in d.items()}, 'cz equal', bool((a['cz'] == b['cz']).all()), flush=True)
+    T = int(os.environ.get('T', '2000'))
+    for S in (512, 1024, 2048, 4096):
+        a, ms1, va = run(1, S, T)
+        b, ms0, vb = run(0, S, T)
+        print(f'{cfg} S={S}: {knob}=1 {ms1:.2f} ms  =0 {ms0:.2f} ms  ratio {ms0 / ms1:.3f}  passed {int(a["passed"].sum())}/{int(b["passed"].sum())} '
+              f'[{va}] vs [{vb}]', flush=True)
+
+
+def cmd_fuzz(args):
+    from cpflow_amd.engine import TemplateEngine
+    from oracle import Oracle
+    N = int(args[0]) if args else 24
+    rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 0)
+    ROTS = ['xyz', 'xz', 'yz', 'zxz', 'xyz', 'z', 'yxz', 'xy', 'zyx']
+    VARIANTS = [dict(CPF_PSTORE='1', CPF_KSPEC='1', CPF_JIT_K='1'), dict(CPF_PSTORE='0', CPF_KSPEC='0', CPF_JIT_K='0'),
+                dict(CPF_PSTORE='1', CPF_KSPEC='0', CPF_JIT_K='0'), dict(CPF_SPLIT='0')]
+    bad, t0 = 0, time.time()
+    for _case in range(N):
+        n = int(rng.choice([3, 3, 3, 4, 5, 6]))
+        pairs = [list(p) for p in itertools.permutations(range(n), 2)]
+        LL = int(rng.integers(1, 4))
+        layer = [pairs[i] for i in rng.choice(len(pairs), LL, replace=False)]
+        if max(max(p) for p in layer) != n - 1:
+            layer[0] = [int(rng.integers(n - 1)), n - 1]     # the layer defines n (topology.py:36-38)
+        K = int(rng.integers(2, 19)) if n == 3 else int(rng.integers(2, 9))
+        rot = ROTS[int(rng.integers(len(ROTS)))]
+        ent = str(rng.choice(['cp', 'cp', 'cp', 'cz', 'cx']))
+        target = rand_u(n, rng)
+        T, S = 6, 3
+        r = float(rng.choice([0.0, 0.004]))
+        orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent)
+        init = orc.initial_angles(int(rng.integers(1 << 20)), S)
+        ref = orc.run(init, np.float64, keep_history=True)
+        for v in (VARIANTS if n == 3 else VARIANTS[:1]):
+            for k in ('CPF_PSTORE', 'CPF_KSPEC', 'CPF_JIT_K', 'CPF_SPLIT'):
+                os.environ.pop(k, None)
+            os.environ.update(v)
+            eng = TemplateEngine(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent)
+            out = {k: x.cpu().numpy() for k, x in eng.optimize(init, keep_history=True).items() if x is not None}
+            e0 = np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max()
+            eh = np.abs(out['history_regloss'] - ref['history_loss']).max()
+            ep = np.abs(out['history_params'][:, :3] - ref['history_params'][:, :3]).max()
+            ok = e0 < 1e-5 and eh < 5e-5 and ep < 2e-4 and (out['cz'] == ref['cz']).all()
+            bad += not ok
+            print(f"{'ok ' if ok else 'BAD'} n={n} layer={layer} K={K} rot={rot} {ent} r={r} {v} [{eng.last_variant()}] first {e0:.1e} hist {eh:.1e} "
+                  f"params {ep:.1e}", flush=True)
+    print('cases', N, 'failures', bad, 'time %.0fs' % (time.time() - t0))
+    return 1 if bad else 0
+
+
+def cmd_fix4(_args):
+    from cpflow_amd.engine import TemplateEngine
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'raw_toff4_star_t14.npz'))
+    S, idx = int(g['num_samples']), set(g['sample_index'].tolist())
+    for env in ({}, {'CPF_FORCE_GENERIC': '1'}, {'CPF_LW': '2'}, {'CPF_DENSE': '0'}):
+        for k in ('CPF_FORCE_GENERIC', 'CPF_LW', 'CPF_DENSE'):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        eng = TemplateEngine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
+        out = {k: v.cpu().numpy() for k, v in eng.optimize(eng.initial_angles(int(g['seed']), S)).items() if v is not None}
+        passed = set(np.flatnonzero(out['passed']).tolist())
+        both = [k for k, j in enumerate(g['sample_index']) if j in passed]
+        same = out['cz'][g['sample_index'][both]] == g['cz'][both]
+        print(env, eng.last_variant(), 'passed', len(passed), 'symmetric difference', sorted(passed ^ idx), 'cz same', same.mean(), flush=True)
+
+
+def cmd_stamps(_args):
+    eng, _ = engine('cfg2', T=500)
+    T = 500
+    out = eng.optimize(eng.initial_angles(0, int(os.environ.get('S', '1024'))), keep_history=True)
+    split = eng.last_variant().startswith('split')
+    h = out['history_regloss'][0, :16].cpu().numpy().astype(np.float64)
+    names = (['forward half', 'wait for other wave', 'loss/track', 'backward half', 'wait for other wave', 'owner', 'wait (owner)', 'loop top'] if split else
+             ['surface fwd', 'blocks fwd', 'loss/track', 'blocks bwd', 'surface bwd', 'owner (Adam, sincos, penalty)', '-', 'loop top'])
+    for w in ((0, 1) if split else (0,)):
+        st = h[8 * w:8 * w + 8]
+        print('wave', 'AB'[w], 'total', st.sum() / T, 'cycles/step')
+        for n, v in zip(names, st):
+            print(f'  {n:32s} {v / T:9.1f} cycles/step  {100 * v / st.sum():5.1f} %')
+
+
+def cmd_static_e2e(_args):
+    import contextlib
+    import io
+    from cpflow_amd import StaticOptions, Synthesize, workloads
+    for S in (10, 1024):
+        syn = Synthesize([[0, 1], [1, 2]], target_unitary=workloads.CCZ, label='ccz')
+        opts = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10, num_samples=S)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                t1 = time.perf_counter()
+                syn._generate_raw(opts)
+                t2 = time.perf_counter()
+                res = syn.static(opts, save_results=False)
+            dt = time.perf_counter() - t0
+            print(f'S={S} rep {rep}: raw stage {1e3 * (t2 - t1):.1f} ms, whole static() {1e3 * (dt - (t2 - t1)):.1f} ms, '
+                  f'{len(res.decompositions)} decompositions, best {min(d.cz_count for d in res.decompositions)} CZ')
+
+
+def cmd_host_api(_args):
+    import ctypes as C
+    from cpflow_amd import _ffi, workloads
+    from cpflow_amd.engine import placements_for
+    lib = _ffi.lib()
+    layer, K, S, T, P = [[0, 1], [1, 2]], 12, 1024, 2000, 93
+    pl, tgt, rot = placements_for(layer, K), np.ascontiguousarray(workloads.CCZ), b'xyz'
+    pb = _ffi.Problem(3, K, pl.ctypes.data, 3, rot, 0, 0, tgt.ctypes.data, _ffi.Penalty(0, np.pi / 2, 2, .05, .05, .05), 1, 0.00055,
+                      0.1, 0.9, 0.999, 1e-8, T, 0.2, 1e-3)
+    out = dict(params=np.empty((S, 2, P), np.float32), regloss=np.empty((S, 2), np.float32), loss=np.empty((S, 2), np.float32),
+               reg=np.empty((S, 2), np.float32), cz=np.empty(S, np.int32), passed=np.empty(S, np.uint8))
+    res = _ffi.Result(*[out[k].ctypes.data for k in ('params', 'regloss', 'loss', 'reg', 'cz', 'passed')])
+    for rep in range(4):
+        t0 = time.perf_counter()
+        rc = lib.cpf_run_static(C.byref(pb), 0, 0, S, 0, S, 0, None, None, C.byref(res))
+        dt = time.perf_counter() - t0
+        assert rc == 0, lib.cpf_last_error()
+        print(f'cpf_run_static rep {rep}: {dt * 1e3:.2f} ms end to end -> {S * T / dt:.3e} sample-steps/s; passed {int(out["passed"].sum())}')
+
+
+COMMANDS = {'perf': cmd_perf, 'one': cmd_one, 'knobs': cmd_knobs, 'ablib': cmd_ablib, 'agree': cmd_agree, 'fuzz': cmd_fuzz, 'fix4': cmd_fix4,
+            'stamps': cmd_stamps, 'static-e2e': cmd_static_e2e, 'host-api': cmd_host_api}
+
+if __name__ == '__main__':
+    if len(sys.argv) < 2 or sys.argv[1] not in COMMANDS:
+        sys.exit(__doc__)
+    sys.exit(COMMANDS[sys.argv[1]](sys.argv[2:]) or 0)
