@@ -53,6 +53,8 @@ SYMBOLS = {
     'cpf_reg_device': (_I32, [_VP, _I64, _VP, _VP, _VP]),
     'cpf_plan_last_kernel_ms': (_I32, [_VP, C.POINTER(C.c_float)]),
     'cpf_plan_last_variant': (_I32, [_VP, C.c_char_p, C.c_size_t]),
+    'cpf_jit_compiles': (_I32, []),
+    'cpf_jit_precompile': (_I32, [C.POINTER(Problem), _I64, C.c_char_p, C.c_size_t]),
     'cpf_run_static': (_I32, [C.POINTER(Problem), _I32, _U32, _I64, _I64, _I64, _I32, _VP, _VP, C.POINTER(Result)]),
 }
 

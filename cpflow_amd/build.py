@@ -8,8 +8,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'cpf_device.h'), os.path.join(HERE, 'csrc', 'cpf_blocks.h'),
-        os.path.join(HERE, 'csrc', 'cpf_layered.h'), os.path.join(HERE, 'csrc', 'cpf_split.h'), os.path.join(HERE, 'csrc', 'cpf_jit.h'), os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_jit.h')
+                if os.path.exists(os.path.join(HERE, 'csrc', h))] + [os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
+JIT_DIR = os.path.join(HERE, 'jit_cache')      # shipped code objects of runtime-specialised kernels (git-ignored, travels with gpurun)
 OUT = os.path.join(HERE, 'libcpflow_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_*_f32 with extra moves,
@@ -32,5 +33,66 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def precompile_shapes():
+    """(layer, rotation strings, block counts, sample counts) of the reference's tutorial / paper runs whose kernels are
+    runtime-specialised: the 4-qubit star of tutorial/results/toff4_star, connected / chain layers on 4 and 5 qubits
+    (paper/results/benchmarks, 'xyz' and 'xz'), twisted 3-qubit layers.  The kernel a launch uses depends on the
+    rotation string, the layer, the angle count per owner thread (bucketed) and on whether the samples fill the chip."""
+    star4, conn4, chain4 = [[0, 1], [0, 2], [0, 3]], [[i, j] for i in range(4) for j in range(i + 1, 4)], [[0, 1], [1, 2], [2, 3]]
+    conn5, chain5 = [[i, j] for i in range(5) for j in range(i + 1, 5)], [[i, i + 1] for i in range(4)]
+    shapes = []
+    for layer in (star4, conn4, chain4):
+        shapes += [(layer, rot, K, S) for rot in ('xyz', 'xz') for K in (14, 23, 29, 40) for S in (100, 2048)]
+    for layer in (conn5, chain5):
+        shapes += [(layer, rot, K, S) for rot in ('xyz', 'xz') for K in (30, 57, 86) for S in (200, 2000)]
+    return shapes
+
+
+def precompile(shapes=None, workers=None, verbose=True):
+    """Fill cpflow_amd/jit_cache/ with the runtime-specialised kernels of `shapes` (no GPU needed: hipcc
+    cross-compiles), so that a GPU box never compiles them.  One process per shape, `workers` at a time."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    build()
+    os.makedirs(JIT_DIR, exist_ok=True)
+    os.chmod(JIT_DIR, 0o700)
+    shapes = precompile_shapes() if shapes is None else shapes
+    env = dict(os.environ, CPF_JIT_CACHE=JIT_DIR)
+
+    def one(shape):
+        code = ('import json, sys; from cpflow_amd.build import _precompile_one; '
+                'print(json.dumps(_precompile_one(*json.loads(sys.argv[1]))))')
+        r = subprocess.run([sys.executable, '-c', code, json.dumps(shape)], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(HERE))
+        if r.returncode:
+            raise RuntimeError(f'precompile of {shape} failed: {r.stderr[-400:]}')
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    seen = set()
+    with ThreadPoolExecutor(max_workers=workers or max(1, (os.cpu_count() or 2) - 1)) as ex:
+        for shape, lines in zip(shapes, ex.map(one, shapes)):
+            for line in lines:
+                if verbose and line not in seen:
+                    print(line)
+                seen.add(line)
+    return sorted(seen)
+
+
+def _precompile_one(layer, rot, K, S):
+    import ctypes as C
+    import numpy as np
+    from . import _ffi
+    from .engine import placements_for, problem_struct
+    n = max(max(p) for p in layer) + 1
+    pl, target, rotb = placements_for(layer, K), np.ascontiguousarray(np.eye(1 << n, dtype=np.complex128)), rot.encode()
+    pb = problem_struct(n, pl, rotb, 'cp', 'hst', target)
+    buf = C.create_string_buffer(4096)
+    rc = _ffi.lib().cpf_jit_precompile(C.byref(pb), int(S), buf, 4096)
+    if rc < 0:
+        raise RuntimeError(_ffi.lib().cpf_last_error().decode())
+    return [x for x in buf.value.decode().splitlines() if x]
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    if '--precompile' in sys.argv:
+        precompile()

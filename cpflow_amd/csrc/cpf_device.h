@@ -849,8 +849,27 @@ __device__ __forceinline__ uint32_t random_bits_at(uint32_t k0, uint32_t k1, uin
     threefry2x32(k0, k1, x0, x1);
     return (i < h) ? x0 : x1;
 }
+// jax.random.normal (jax 0.3.x _normal_real): u = uniform(key, minval = nextafter(-1, 0), maxval = 1), sqrt(2) * erf_inv(u).
+// erf_inv restates XLA's single-precision ErfInv (Giles' polynomial in w = -log((1 - x)(1 + x))): third-party arithmetic, and
+// no result file of the reference uses cp_distribution = 'normal', so this branch is "parity unpinned" (DESIGN.md).
+__device__ __forceinline__ float erfinv_xla_f32(float x) {
+    float w = -log1pf(-x * x);
+    const bool lt = w < 5.0f;
+    w = lt ? w - 2.5f : sqrtf(w) - 3.0f;
+    float p = lt ? 2.81022636e-08f : -0.000200214257f;
+    p = fmaf(p, w, lt ? 3.43273939e-07f : 0.000100950558f);
+    p = fmaf(p, w, lt ? -3.5233877e-06f : 0.00134934322f);
+    p = fmaf(p, w, lt ? -4.39150654e-06f : -0.00367342844f);
+    p = fmaf(p, w, lt ? 0.00021858087f : 0.00573950773f);
+    p = fmaf(p, w, lt ? -0.00125372503f : -0.0076224613f);
+    p = fmaf(p, w, lt ? -0.00417768164f : 0.00943887047f);
+    p = fmaf(p, w, lt ? 0.246640727f : 1.00167406f);
+    p = fmaf(p, w, lt ? 1.50140941f : 2.83297682f);
+    return p * x;
+}
+// cp_mode: 0 'uniform', 1 '0' (CP angles zero), 2 'normal' (CP angles 1.5 * normal(split(key')[1]), cp_utils.py:38-40)
 __global__ void k_initial_angles(uint32_t seed, uint32_t s_total, uint32_t first, uint32_t count, uint32_t P,
-                                 const uint8_t* pkind, int cp_zero, float* out) {
+                                 const uint8_t* pkind, int cp_mode, float* out) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint64_t)count * P) return;
     const uint32_t j = (uint32_t)(idx / P), i = (uint32_t)(idx % P);
@@ -861,7 +880,17 @@ __global__ void k_initial_angles(uint32_t seed, uint32_t s_total, uint32_t first
     float f = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
     f = __fmul_rn(f, 6.2831855f);
     f = fmaxf(0.f, f);
-    if (cp_zero && pkind[i]) f = 0.f;
+    if (cp_mode == 1 && pkind[i]) f = 0.f;
+    if (cp_mode == 2 && pkind[i]) {
+        // key, subkey = split(key) a second time: key = split(k)[0], subkey = split(key)[1]
+        const uint32_t n0 = random_bits_at(ka, kb, 4u, 0u), n1 = random_bits_at(ka, kb, 4u, 1u);
+        const uint32_t t0 = random_bits_at(n0, n1, 4u, 2u), t1 = random_bits_at(n0, n1, 4u, 3u);
+        const uint32_t nb = random_bits_at(t0, t1, P, i);
+        const float lo = -0.99999994f;                                  // nextafter(-1, 0); maxval - minval rounds to 2
+        float u = __fadd_rn(__fmul_rn(__uint_as_float((nb >> 9) | 0x3F800000u) - 1.0f, 2.0f), lo);
+        u = fmaxf(lo, u);
+        f = __fmul_rn(1.5f, __fmul_rn(1.41421354f, erfinv_xla_f32(u)));
+    }
     out[idx] = f;
 }
 

@@ -1,27 +1,38 @@
-// cpflow_amd: runtime specialisation of the layered kernel (cpf_layered.h) with hiprtc.
+// cpflow_amd: runtime specialisation of the layer-specialised kernels (cpf_layered.h, cpf_split.h, cpf_dense.h).
 //
-// A plan's circuit is fixed (qubits, rotation string, layer), so its block loop can be straight-line code.
-// The ahead-of-time build carries that specialisation only for the reference's two 3-qubit layers; every
-// other (n, waves per sample, rotation string, layer) is instantiated here on first use: the template
-// arguments are spliced into a three-line translation unit, compiled for gfx950 (1-6 s; hipcc --genco as a
-// child process, hiprtc as fallback), and the code object is cached in memory and on disk ($CPF_JIT_CACHE
-// or ~/.cache/cpflow_amd).  If anything fails the caller
-// falls back to the ahead-of-time generic kernel.  CPF_JIT=0 disables this path.
+// A plan's circuit is fixed (qubits, rotation string, layer), so its block loop can be straight-line code.  The
+// ahead-of-time build carries that specialisation for the BASELINE shapes; every other (n, waves per sample, rotation
+// string, layer) is instantiated on first use: the template arguments are spliced into a three-line translation unit
+// and compiled for gfx950.  Where the code object comes from, in this order:
+//   1. <library dir>/jit_cache/   shipped with the library (python -m cpflow_amd.build --precompile fills it in the
+//                                 build container for the reference's tutorial / paper shapes: no compiler at run time)
+//   2. $CPF_JIT_CACHE or ~/.cache/cpflow_amd   (per user, mode 0700)
+//   3. a compile: hipcc --genco as a child process (posix_spawn, no shell; profiler preloads stripped from its
+//      environment), hiprtc in-process as the fallback and whenever a profiler is attached to this process.
+// CPF_JIT_FORBID_COMPILE=1 turns step 3 into an error (a test can prove that a box never compiles), CPF_JIT=0 disables
+// the whole path.  Failures are remembered per kernel, so a launch loop does not re-run a failing compiler.
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
+
+extern char** environ;
 
 namespace cpf_jit {
 
@@ -47,124 +58,185 @@ inline uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
-inline bool make_dirs(const std::string& d) {
+// a directory this user owns and nobody else can write (a planted .hsaco would be loaded with hipModuleLoadData)
+inline bool private_dir(const std::string& d) {
     std::string acc;
     for (size_t i = 0; i <= d.size(); i++)
-        if (i == d.size() || d[i] == '/') { if (!acc.empty()) mkdir(acc.c_str(), 0755); if (i < d.size()) acc += '/'; }
+        if (i == d.size() || d[i] == '/') { if (!acc.empty()) mkdir(acc.c_str(), 0700); if (i < d.size()) acc += '/'; }
         else acc += d[i];
     struct stat st;
-    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && access(d.c_str(), W_OK) == 0;
+    return stat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & 022) == 0 &&
+           access(d.c_str(), W_OK) == 0;
 }
+inline std::string shipped_dir() { return lib_dir() + "/jit_cache"; }
 inline std::string cache_dir() {
     const char* e = getenv("CPF_JIT_CACHE");
     const std::string first = e ? std::string(e) : std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/cpflow_amd";
-    if (make_dirs(first)) return first;
+    if (private_dir(first)) return first;
     const std::string fallback = "/tmp/cpflow_amd_cache_" + std::to_string((long)getuid());      // read-only home
-    make_dirs(fallback);
-    return fallback;
+    if (private_dir(fallback)) return fallback;
+    char tmpl[] = "/tmp/cpflow_amd_XXXXXX";                                                       // someone else owns that name
+    const char* made = mkdtemp(tmpl);
+    return made ? std::string(made) : std::string();
 }
 
-struct Kernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; };
+// a profiler attached to this process (rocprofv3 preloads its tool library, which initialises the GPU in every child
+// that inherits the variables): compile in-process then
+inline bool profiler_attached() {
+    for (const char* v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB", "ROCPROF_OUTPUT_PATH"})
+        if (getenv(v)) return true;
+    const char* pre = getenv("LD_PRELOAD");
+    return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer"));
+}
 
-// key -> loaded kernel, per process (and per device: the key carries the device index)
-inline std::map<std::string, Kernel>& table() { static std::map<std::string, Kernel> t; return t; }
-inline std::mutex& table_mutex() { static std::mutex m; return m; }
+// hipcc as a child process: argv, no shell; stdout / stderr to `log`; profiler and preload variables removed
+inline int run_hipcc(const std::vector<std::string>& argv, const std::string& log) {
+    std::vector<char*> av;
+    for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    std::vector<std::string> envs;
+    for (char** e = environ; e && *e; e++) {
+        const std::string kv(*e);
+        if (kv.rfind("LD_PRELOAD=", 0) == 0 || kv.rfind("ROCP", 0) == 0 || kv.rfind("HSA_TOOLS", 0) == 0 || kv.rfind("ROCTRACER", 0) == 0)
+            continue;
+        envs.push_back(kv);
+    }
+    std::vector<char*> ev;
+    for (const std::string& a : envs) ev.push_back(const_cast<char*>(a.c_str()));
+    ev.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), ev.data());
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return -1;
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0) { if (errno != EINTR) return -1; }
+    return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
 
-// Returns nullptr (and fills err) when the kernel cannot be produced.
-// split: the two-ended kernel (cpf_split.h; nq == 3, lw ignored, 128 threads) instead of the layered one.
-inline hipFunction_t get_layered(int device, int nq, int lw, int rot_code, int ppt, int mstore, const std::vector<int>& ud,
-                                 std::string* err, bool split = false) {
-    std::ostringstream name;
-    name << (split ? "cpf::k_cp_split<" : "cpf::k_cp_layered<") << nq << ", " << lw << ", " << rot_code << ", " << ppt << ", " << mstore;
-    for (int v : ud) name << ", " << v;
-    name << ">";
-    const std::string expr = name.str();
-    const std::string key = "dev" + std::to_string(device) + ":" + expr;
-    std::lock_guard<std::mutex> lock(table_mutex());
-    auto it = table().find(key);
-    if (it != table().end()) return it->second.fn;
+// what to build: `header` is the file under csrc/ that defines `body` (e.g. "cpf_layered.h",
+// "cpf::layered_body<4, 0, 8451, 3, 0, 0, 1, 1, 2, 2, 3>"), `threads` the workgroup size
+struct Spec { std::string header, body; int threads = 64; };
 
+struct Code { std::string bytes, backend, error; bool compiled = false; };    // backend: "hipcc" | "hiprtc"
+
+inline std::atomic<int>& compile_counter() { static std::atomic<int> n{0}; return n; }
+
+// Produce the code object of a spec without touching the GPU (cache look-ups, then a compile unless forbidden).
+inline Code build(const Spec& sp) {
+    Code out;
     const std::string inc = lib_dir() + "/csrc";
-    const std::string hdrs = read_file(inc + "/cpf_device.h") + read_file(inc + "/cpf_blocks.h") + read_file(inc + "/cpf_layered.h") +
-                             (split ? read_file(inc + "/cpf_split.h") : std::string());
-    if (hdrs.size() < 1000) { if (err) *err = "kernel headers not found under " + inc; return nullptr; }
+    std::string hdrs;
+    for (const char* h : {"cpf_device.h", "cpf_blocks.h", "cpf_layered.h", "cpf_split.h", "cpf_dense.h"}) hdrs += read_file(inc + "/" + h);
+    if (hdrs.size() < 1000) { out.error = "kernel headers not found under " + inc; return out; }
     // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
-    std::ostringstream targs;
-    if (!split) targs << nq << ", " << lw << ", ";
-    targs << rot_code << ", " << ppt << ", " << mstore;
-    for (int v : ud) targs << ", " << v;
-    const std::string src = std::string(split ? "#include \"cpf_split.h\"\n" : "#include \"cpf_layered.h\"\n") +
-                            "extern \"C\" __global__ __launch_bounds__(" + std::to_string(split ? 128 : (64 << lw)) +
-                            ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    cpf::" +
-                            (split ? "split_body<" : "layered_body<") + targs.str() + ">(a);\n}\n";
-    // Backend: the offline compiler as a child process by default.  hiprtc builds the same source with the
-    // same flags, but on the MI355X boxes its code came out 2x slower (SGPR spills through v_writelane /
-    // v_readlane, 4477 vs 3536 instructions for the 3-qubit chain kernel: 20.6 ms vs 11.0 ms on config 2);
-    // it stays as the fallback when no hipcc is installed.  CPF_JIT_BACKEND=hiprtc|hipcc overrides.
+    const std::string src = "#include \"" + sp.header + "\"\nextern \"C\" __global__ __launch_bounds__(" + std::to_string(sp.threads) +
+                            ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    " + sp.body + "(a);\n}\n";
+    // Backend: the offline compiler as a child process by default.  hiprtc builds the same source with the same flags,
+    // but on the MI355X boxes its code came out 2x slower (SGPR spills through v_writelane / v_readlane, 4477 vs 3536
+    // instructions for the 3-qubit chain kernel: 20.6 ms vs 11.0 ms on config 2); it is the fallback when no hipcc is
+    // installed and the choice under a profiler.  CPF_JIT_BACKEND=hiprtc|hipcc overrides.
     const char* be = getenv("CPF_JIT_BACKEND");
     const char* hipcc_env = getenv("HIPCC");
     const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
     struct stat st_;
     const bool have_hipcc = stat(hipcc.c_str(), &st_) == 0;
-    const bool use_hipcc = be ? std::string(be) == "hipcc" : have_hipcc;
-    char hname[64];
-    snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src + (use_hipcc ? "hipcc" : "hiprtc"), fnv1a(hdrs)));
-    const std::string cpath = cache_dir() + "/" + hname + ".hsaco";
-    std::string code = read_file(cpath);
-    const std::string lowered = "cpf_jit_kernel";
+    auto name_for = [&](const char* backend) {
+        char hname[64];
+        snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src + backend, fnv1a(hdrs)));
+        return std::string(hname) + ".hsaco";
+    };
+    // an object built by hipcc is the preferred one wherever it is found, whatever could be built here and now
+    for (const char* backend : {"hipcc", "hiprtc"}) {
+        if (be && std::string(be) != backend) continue;
+        for (const std::string& dir : {shipped_dir(), cache_dir()}) {
+            if (dir.empty()) continue;
+            out.bytes = read_file(dir + "/" + name_for(backend));
+            if (!out.bytes.empty()) { out.backend = backend; return out; }
+        }
+    }
+    { const char* f = getenv("CPF_JIT_FORBID_COMPILE");
+      if (f && f[0] == '1') { out.error = "run-time compile forbidden (CPF_JIT_FORBID_COMPILE=1) and no cached object for " + sp.body; return out; } }
+    const bool use_hipcc = be ? std::string(be) == "hipcc" : (have_hipcc && !profiler_attached());
+    const std::string cdir = cache_dir();
+    if (cdir.empty()) { out.error = "no writable private cache directory"; return out; }
     // ranks of one job may build the same kernel at the same time: private temporaries, atomic rename
-    const std::string tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
-    if (code.empty() && use_hipcc) {
-        // offline compiler as a subprocess (same flags as the ahead-of-time build)
+    if (use_hipcc) {
+        const std::string cpath = cdir + "/" + name_for("hipcc"), tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
         const std::string spath = tmp + ".hip";
-        std::ofstream(spath) << src;
-        const std::string cmd = hipcc + " --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-signed-zeros "
-                                "--genco -I" + inc + " -o " + tmp + " " + spath + " > " + tmp + ".log 2>&1";
-        if (system(cmd.c_str()) == 0) {
-            code = read_file(tmp);
+        { std::ofstream o(spath); o << src; }
+        const int rc = run_hipcc({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "--genco",
+                                  "-I" + inc, "-o", tmp, spath}, tmp + ".log");
+        unlink(spath.c_str());
+        if (rc == 0) {
+            out.bytes = read_file(tmp);
             rename(tmp.c_str(), cpath.c_str());
             unlink((tmp + ".log").c_str());
-        } else if (err) {
-            *err = "hipcc --genco failed, see " + tmp + ".log; ";
+            if (!out.bytes.empty()) { out.backend = "hipcc"; out.compiled = true; compile_counter()++; return out; }
         }
-        unlink(spath.c_str());
+        out.error = "hipcc --genco failed (exit " + std::to_string(rc) + "), see " + tmp + ".log; ";
+        if (be) return out;
     }
-    if (code.empty()) {
-        hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, src.c_str(), "cpf_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-            if (err) *err = "hiprtcCreateProgram failed";
-            return nullptr;
-        }
-        const std::string i1 = "-I" + inc, i2 = "-I/opt/rocm/include";
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros",
-                              i1.c_str(), i2.c_str()};
-        const hiprtcResult r = hiprtcCompileProgram(prog, 7, opts);
-        if (r != HIPRTC_SUCCESS) {
-            size_t n = 0;
-            hiprtcGetProgramLogSize(prog, &n);
-            std::string log(n, '\0');
-            if (n) hiprtcGetProgramLog(prog, &log[0]);
-            if (err) *err = "hiprtc: " + log.substr(0, 400);
-            hiprtcDestroyProgram(&prog);
-            return nullptr;
-        }
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "cpf_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { out.error += "hiprtcCreateProgram failed"; return out; }
+    const std::string i1 = "-I" + inc, i2 = "-I/opt/rocm/include";
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", i1.c_str(), i2.c_str()};
+    if (hiprtcCompileProgram(prog, 7, opts) != HIPRTC_SUCCESS) {
         size_t n = 0;
-        hiprtcGetCodeSize(prog, &n);
-        code.assign(n, '\0');
-        hiprtcGetCode(prog, &code[0]);
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        out.error += "hiprtc: " + log.substr(0, 400);
         hiprtcDestroyProgram(&prog);
-        { std::ofstream o(tmp, std::ios::binary); o << code; }
-        rename(tmp.c_str(), cpath.c_str());
+        return out;
     }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    out.bytes.assign(n, '\0');
+    hiprtcGetCode(prog, &out.bytes[0]);
+    hiprtcDestroyProgram(&prog);
+    const std::string cpath = cdir + "/" + name_for("hiprtc"), tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
+    { std::ofstream o(tmp, std::ios::binary); o << out.bytes; }
+    rename(tmp.c_str(), cpath.c_str());
+    out.backend = "hiprtc"; out.compiled = true; out.error.clear(); compile_counter()++;
+    return out;
+}
+
+struct Kernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; std::string backend, error; };
+
+// key -> loaded kernel (or remembered failure), per process and device
+inline std::map<std::string, Kernel>& table() { static std::map<std::string, Kernel> t; return t; }
+inline std::mutex& table_mutex() { static std::mutex m; return m; }
+
+// Returns the loaded kernel; fn == nullptr (with .error set) when it cannot be produced.
+inline const Kernel& get(int device, const Spec& sp) {
+    const std::string key = "dev" + std::to_string(device) + ":" + sp.body;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    auto it = table().find(key);
+    if (it != table().end()) return it->second;
     Kernel k;
-    if (hipModuleLoadData(&k.module, code.data()) != hipSuccess ||
-        hipModuleGetFunction(&k.fn, k.module, lowered.c_str()) != hipSuccess) {
-        if (err) *err = "hipModuleLoadData / hipModuleGetFunction failed for " + expr;
-        table()[key] = Kernel{};          // do not retry every launch
-        return nullptr;
+    const Code code = build(sp);
+    k.backend = code.backend;
+    if (code.bytes.empty()) k.error = code.error;
+    else if (hipModuleLoadData(&k.module, code.bytes.data()) != hipSuccess || hipModuleGetFunction(&k.fn, k.module, "cpf_jit_kernel") != hipSuccess) {
+        k.fn = nullptr;
+        k.error = "hipModuleLoadData / hipModuleGetFunction failed for " + sp.body;
     }
-    table()[key] = k;
-    return k.fn;
+    return table()[key] = k;          // failures too: do not retry every launch
+}
+
+inline std::string body_expr(const char* fn, std::initializer_list<int> head, const std::vector<int>& ud) {
+    std::ostringstream s;
+    s << "cpf::" << fn << "<";
+    bool first = true;
+    for (int v : head) { s << (first ? "" : ", ") << v; first = false; }
+    for (int v : ud) s << ", " << v;
+    s << ">";
+    return s.str();
 }
 
 }  // namespace cpf_jit

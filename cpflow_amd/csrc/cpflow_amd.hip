@@ -253,61 +253,103 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
     return false;
 }
 
-// Runtime-specialised layered kernel (cpf_layered.h through hiprtc).  lw = log2(waves per sample).
-bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
+// ---- runtime-specialised kernels (cpf_jit.h).  Which kernels a (plan, S, lw) launch would try, in order of
+// preference: used by the launch path and by cpf_jit_precompile (which builds them without a GPU).
+struct JitCandidate { cpf_jit::Spec spec; size_t lds = 0; std::string tag; };
+
+int ppt_bucket(int ppt) {          // angles per owner thread, rounded up to a few sizes so that adaptive searches over K share kernels
+    for (int b : {1, 2, 3, 4, 6, 8, 12}) if (ppt <= b) return b;
+    return ppt;
+}
+
+std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, int lw, int64_t S) {
+    std::vector<JitCandidate> out;
     plan->jit_note.clear();
-    if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE) return false;
-    if (plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP || plan->K < 1) return false;
-    if (plan->n_rot < 1 || plan->n_rot > 3 || plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
-    const int threads = 64 << lw, ppt = (a.P + threads - 1) / threads;
-    if (ppt > 12) { plan->jit_note = "too many angles per thread"; return false; }
+    if (plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP || plan->K < 1) return out;
+    if (plan->n_rot < 1 || plan->n_rot > 3 || plan->layer_ud.empty() || plan->layer_ud.size() > 32) return out;
+    const int threads = 64 << lw, ppt = ppt_bucket((P + threads - 1) / threads);
+    if (ppt > 12) { plan->jit_note = "too many angles per thread"; return out; }
     int kinds[3] = {0, 0, 0};
     for (int i = 0; i < plan->n_rot; i++) kinds[i] = plan->rot[i] == 'x' ? cpf::OP_RX : (plan->rot[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
     const int rot_code = cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]);
-    size_t lds = 0;
-    int mstore = 0;
+    cpf::KArgs a{};
+    a.loss_kind = loss_kind;
     const char* jk = getenv("CPF_JIT_K");                                        // opt-in: one build per block count
     const bool jit_k = jk && jk[0] == '1';
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
-        const int sppt = (a.P + 127) / 128;
+        const int sppt = ppt_bucket((P + 127) / 128);
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
         const int smstore = (states_fit(plan, S, rot_code, slds2) ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
-        const size_t slds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
-        std::string serr;
-        hipFunction_t sfn = slds <= 64 * 1024 ? cpf_jit::get_layered(plan->device, 3, 0, rot_code, sppt, smstore, plan->layer_ud, &serr, true) : nullptr;
-        if (sfn) {
-            cpf::KArgs args = a;
-            void* params[] = {&args};
-            const hipError_t e = hipModuleLaunchKernel(sfn, (unsigned)S, 1, 1, 128, 1, 1, (unsigned)slds, stream, params, nullptr);
-            *rc = e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
-            plan->variant = std::string((smstore & 3) == 2 ? "split/jit waves=2 states" : "split/jit waves=2") + (smstore >> 2 ? " K" : "");
-            return true;
-        }
-        plan->jit_note = serr;          // fall through to the one-wave kernel
+        JitCandidate c;
+        c.lds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
+        c.spec = {"cpf_split.h", cpf_jit::body_expr("split_body", {rot_code, sppt, smstore}, plan->layer_ud), 128};
+        c.tag = std::string((smstore & 3) == 2 ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (smstore >> 2 ? " K" : "");
+        if (c.lds <= 64 * 1024) out.push_back(c);
     }
+    int mstore = 0;
     if (plan->NQ == 3 && cpf::layered_merge(3, lw, rot_code)) {
         const size_t with = (size_t)cpf::LayeredLds<3>::total(plan->K, 1, true) * sizeof(float);
         mstore = (with <= 64 * 1024 && phases_fit(plan, S, with)) ? 1 : 0;
     }
+    size_t lds = 0;
     switch (plan->NQ) {
         case 3: lds = cpf::LayeredLds<3>::total(plan->K, 1 << lw, mstore != 0); break;
         case 4: lds = cpf::LayeredLds<4>::total(plan->K, 1 << lw, false); break;
         case 5: lds = cpf::LayeredLds<5>::total(plan->K, 1 << lw, false); break;
         case 6: lds = cpf::LayeredLds<6>::total(plan->K, 1 << lw, false); break;
-        default: return false;
+        default: return out;
     }
     lds *= sizeof(float);
-    if (lds > 64 * 1024) { plan->jit_note = "LDS footprint above 64 KiB"; return false; }
-    std::string err;
-    hipFunction_t fn = cpf_jit::get_layered(plan->device, plan->NQ, lw, rot_code, ppt, mstore, plan->layer_ud, &err);
-    if (!fn) { plan->jit_note = err; return false; }
-    cpf::KArgs args = a;
-    void* params[] = {&args};
-    const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
-    plan->variant = std::string("layered/jit waves=") + (lw ? "4" : "1");
-    if (e != hipSuccess) { *rc = fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e)); return true; }
-    *rc = 0;
-    return true;
+    if (lds > 64 * 1024) { plan->jit_note = "LDS footprint above 64 KiB"; return out; }
+    JitCandidate c;
+    c.lds = lds;
+    c.spec = {"cpf_layered.h", cpf_jit::body_expr("layered_body", {plan->NQ, lw, rot_code, ppt, mstore}, plan->layer_ud), threads};
+    c.tag = std::string("layered/jit(%s) waves=") + (lw ? "4" : "1");
+    out.push_back(c);
+    return out;
+}
+
+std::string tag_with_backend(const std::string& tag, const std::string& backend) {
+    std::string t = tag;
+    const size_t k = t.find("%s");
+    if (k != std::string::npos) t.replace(k, 2, backend);
+    return t;
+}
+
+// lw = log2(waves per sample).  Returns true when a specialised kernel was launched (or a hard error is in *rc).
+bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
+    if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE) return false;
+    for (const JitCandidate& c : jit_candidates(plan, a.P, a.loss_kind, lw, S)) {
+        const cpf_jit::Kernel& k = cpf_jit::get(plan->device, c.spec);
+        if (!k.fn) {
+            plan->jit_note = k.error;
+            if (k.error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", k.error.c_str()); return true; }
+            continue;          // next candidate, then the generic kernel
+        }
+        cpf::KArgs args = a;
+        void* params[] = {&args};
+        const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)c.spec.threads, 1, 1, (unsigned)c.lds, stream, params, nullptr);
+        plan->variant = tag_with_backend(c.tag, k.backend);
+        *rc = e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+        return true;
+    }
+    return false;
+}
+
+// waves per sample: 1 when there are enough samples to fill the SIMDs, else 4 (columns split over waves)
+int choose_lw(const cpf_plan* plan, int64_t S) {
+    const int64_t simds = (int64_t)plan->num_cu * 4;
+    int lw = 0;
+    // measured on MI355X: n=4 S=2048: 1 wave 9.9 ms vs 4 waves 17.0 ms; n=5 S=1000: 1 wave 22.4 ms vs 4 waves 29.6 ms
+    switch (plan->NQ) {
+        case 4: lw = (S >= simds) ? 0 : 2; break;
+        case 5: lw = (2 * S >= simds) ? 0 : 2; break;
+        case 6: lw = 2; break;
+        default: lw = 0;
+    }
+    { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
+    if (plan->NQ == 6) lw = 2;
+    return lw;
 }
 
 // Variant choice: one workgroup per sample; more waves per sample when there are too few
@@ -320,18 +362,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
     // kernel; 3. generic per-gate kernel
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
-    const int64_t simds = (int64_t)plan->num_cu * 4;
-    // waves per sample: 1 when there are enough samples to fill the SIMDs, else 4 (columns split over waves)
-    int lw = 0;
-    // measured on MI355X: n=4 S=2048: 1 wave 9.9 ms vs 4 waves 17.0 ms; n=5 S=1000: 1 wave 22.4 ms vs 4 waves 29.6 ms
-    switch (plan->NQ) {
-        case 4: lw = (S >= simds) ? 0 : 2; break;
-        case 5: lw = (2 * S >= simds) ? 0 : 2; break;
-        case 6: lw = 2; break;
-        default: lw = 0;
-    }
-    { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
-    if (plan->NQ == 6) lw = 2;
+    const int lw = choose_lw(plan, S);
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) return rc;
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
@@ -341,6 +372,27 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
         case 5: return lw == 0 ? launch_variant<5, 0>(a, S, stream) : launch_variant<5, 2>(a, S, stream);
         case 6: return launch_variant<6, 2>(a, S, stream);
         default: return fail(-2, "unsupported kernel width %d", plan->NQ);
+    }
+}
+
+// The part of a plan that needs no device: sizes, rotation string, kernel width, the layer (shortest period of the
+// placement sequence) the specialised kernels are built around.
+void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
+    pl->n = pb->n_qubits; pl->K = pb->num_blocks; pl->n_rot = pb->n_rot; pl->entangler = pb->entangler;
+    pl->nb = 2 * pb->n_rot + (pb->entangler == CPF_ENTANGLER_CP ? 1 : 0);
+    pl->P = 3 * pl->n + pl->nb * pl->K;
+    pl->T = pb->num_iterations;
+    pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
+    { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
+    { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
+    pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
+    pl->layer_ud.clear();
+    for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
+        bool periodic = true;
+        for (int b = L; b < pl->K && periodic; b++)
+            periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
+                       pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
+        if (periodic) pl->layer_ud.assign(pb->placements, pb->placements + 2 * L);
     }
 }
 
@@ -365,14 +417,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     CPF_HIP(hipSetDevice(device));
     cpf_plan* pl = new cpf_plan();
     pl->device = device;
-    pl->n = pb->n_qubits; pl->K = pb->num_blocks; pl->n_rot = pb->n_rot; pl->entangler = pb->entangler;
-    pl->nb = 2 * pb->n_rot + (pb->entangler == CPF_ENTANGLER_CP ? 1 : 0);
-    pl->P = 3 * pl->n + pl->nb * pl->K;
-    pl->T = pb->num_iterations;
-    pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
-    { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
-    { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
-    pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
+    fill_plan_shape(pb, pl);
     const int n = pl->n, NQ = pl->NQ, N = 1 << n, D = 1 << NQ, P = pl->P;
 
     // ---- gate program (main.py:106-146): surface Rz Rx Rz per qubit, then per block
@@ -405,14 +450,6 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     std::vector<int32_t> pgate((size_t)P, 0);
     for (int g = 0; g < pl->G; g++)
         if (prog[g].x != cpf::OP_CZ && prog[g].x != cpf::OP_CX) pgate[prog[g].w] = g;
-    // shortest period of the placement sequence = the layer the specialised kernels are built around
-    for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
-        bool periodic = true;
-        for (int b = L; b < pl->K && periodic; b++)
-            periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
-                       pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
-        if (periodic) pl->layer_ud.assign(pb->placements, pb->placements + 2 * L);
-    }
     // ---- target, used as complex64, embedded as V (x) I when the kernel is wider than the problem
     std::vector<float2> tgt((size_t)D * D, make_float2(0.f, 0.f));
     const int d = NQ - n;
@@ -585,6 +622,25 @@ int32_t cpf_reg_device(const cpf_plan* plan, int64_t count, const float* d_theta
                        plan->base, d_theta, count, d_reg);
     CPF_HIP(hipGetLastError());
     return 0;
+}
+
+int32_t cpf_jit_compiles(void) { return cpf_jit::compile_counter().load(); }
+
+int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf, size_t size) {
+    if (int rc = validate(pb)) return rc;
+    cpf_plan pl;                       // shape only: nothing here touches a device
+    fill_plan_shape(pb, &pl);
+    std::string report;
+    int built = 0;
+    const int loss_kind = pb->loss_kind == CPF_LOSS_RELATIVE_PHASE ? 2 : 0;
+    for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, choose_lw(&pl, num_samples), num_samples)) {
+        const cpf_jit::Code code = cpf_jit::build(c.spec);
+        if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", c.spec.body.c_str(), code.error.c_str());
+        report += tag_with_backend(c.tag, code.backend) + (code.compiled ? " [built] " : " [cached] ") + c.spec.body + "\n";
+        built++;
+    }
+    if (buf && size) snprintf(buf, size, "%s", report.c_str());
+    return built;
 }
 
 int32_t cpf_run_static(const cpf_problem* problem, int32_t device, uint32_t seed, int64_t num_samples_total,

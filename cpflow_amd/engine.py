@@ -33,6 +33,24 @@ def num_qubits_from_layer(layer):
     return max(int(q) for pair in layer for q in pair) + 1
 
 
+def problem_struct(num_qubits, placements, rot, entangler, loss, target, penalty='linear', xmax=math.pi / 2, ymax=2.0,
+                   plato_0=0.05, plato_1=0.05, plato_2=0.05, use_reg=True, r=0.00055, learning_rate=0.1, num_gd_iterations=2000,
+                   threshold_cp=0.2, entry_loss=1e-3):
+    """The `cpf_problem` of include/cpflow_amd.h from host arrays (the caller keeps placements / rot / target alive)."""
+    pb = _ffi.Problem()
+    pb.n_qubits, pb.num_blocks = int(num_qubits), len(placements)
+    pb.placements = placements.ctypes.data
+    pb.n_rot, pb.rot_axes = len(rot), rot
+    pb.entangler, pb.loss_kind = _ffi.ENTANGLER[entangler], _ffi.LOSS[loss]
+    pb.target = target.ctypes.data
+    pb.penalty = _ffi.Penalty(_ffi.PENALTY[penalty], xmax, ymax, plato_0, plato_1, plato_2)
+    pb.use_reg, pb.r = int(bool(use_reg)), float(r)
+    pb.lr, pb.b1, pb.b2, pb.eps = float(learning_rate), 0.9, 0.999, 1e-8
+    pb.num_iterations = int(num_gd_iterations)
+    pb.threshold_cp, pb.entry_loss = float(threshold_cp), float(entry_loss)
+    return pb
+
+
 class TemplateEngine:
     def __init__(self, layer, num_cp_gates, target_unitary, rotation_gates='xyz', r=0.00055,
                  entangler='cp', use_reg=True, penalty='linear', xmax=math.pi / 2, ymax=2.0,
@@ -66,17 +84,8 @@ class TemplateEngine:
         self._rot = self.rotation_gates.encode()
         if entangler not in _ffi.ENTANGLER:
             raise TypeError(f"Gate '{entangler}' not implemented.")
-        pb = _ffi.Problem()
-        pb.n_qubits, pb.num_blocks = self.num_qubits, self.num_cp_gates
-        pb.placements = self._placements.ctypes.data
-        pb.n_rot, pb.rot_axes = len(self._rot), self._rot
-        pb.entangler, pb.loss_kind = _ffi.ENTANGLER[entangler], _ffi.LOSS[loss]
-        pb.target = self._target.ctypes.data
-        pb.penalty = _ffi.Penalty(_ffi.PENALTY[penalty], xmax, ymax, plato_0, plato_1, plato_2)
-        pb.use_reg, pb.r = int(bool(use_reg)), float(r)
-        pb.lr, pb.b1, pb.b2, pb.eps = float(learning_rate), 0.9, 0.999, 1e-8
-        pb.num_iterations = int(num_gd_iterations)
-        pb.threshold_cp, pb.entry_loss = float(threshold_cp), float(entry_loss)
+        pb = problem_struct(self.num_qubits, self._placements, self._rot, entangler, loss, self._target, penalty,
+                            xmax, ymax, plato_0, plato_1, plato_2, use_reg, r, learning_rate, num_gd_iterations, threshold_cp, entry_loss)
         self._problem = pb
         self.num_gd_iterations = int(num_gd_iterations)
         handle = C.c_void_p()
@@ -119,13 +128,14 @@ class TemplateEngine:
     # ------------------------------------------------------------------ calls
     def initial_angles(self, seed, num_samples_total, first=0, count=None, cp_dist='uniform'):
         """float32[count, P] on the device; row j is what jax draws for global sample first+j."""
-        if cp_dist not in ('uniform', '0'):
-            raise NotImplementedError(f"cp_distribution '{cp_dist}' is not available on the device path")
+        modes = {'uniform': 0, '0': 1, 'normal': 2}
+        if cp_dist not in modes:           # the reference prints "cp_dist ... not supported" and returns None (cp_utils.py:41-42)
+            raise ValueError(f"cp_dist '{cp_dist}' not supported")
         count = int(num_samples_total) - int(first) if count is None else int(count)
         out = self._empty((count, self.num_angles))
         _ffi.check(self._lib.cpf_initial_angles_device(
             self._plan, int(seed) & 0xFFFFFFFF, int(num_samples_total), int(first), count,
-            1 if cp_dist == '0' else 0, self._ptr(out), self._stream()))
+            modes[cp_dist], self._ptr(out), self._stream()))
         return out
 
     def optimize(self, init, frozen=None, keep_history=False):

@@ -96,7 +96,8 @@ double cpf_plan_flops_per_sample_step(const cpf_plan* plan);
 
 /* Initial angles (main.py:541-548): rows [first, first+count) of the
  * num_samples_total x P matrix jax would draw from PRNGKey(seed).
- * cp_zero != 0 implements cp_distribution == '0'. */
+ * cp_zero selects cp_distribution (cp_utils.py:34-40): 0 'uniform', 1 '0' (CP angles start at zero), 2 'normal'
+ * (CP angles 1.5 * normal; jax.random.normal restated, parity unpinned: no reference result file uses it). */
 int32_t cpf_initial_angles_device(const cpf_plan* plan, uint32_t seed, int64_t num_samples_total,
                                   int64_t first, int64_t count, int32_t cp_zero,
                                   float* d_angles /*[count][P]*/, void* stream);
@@ -131,9 +132,20 @@ int32_t cpf_unitary_device(const cpf_plan* plan, int64_t num_samples, const floa
 /* Duration in ms of the last cpf_optimize_device kernel of this plan, measured with HIP events
  * on the launch stream (blocks until that kernel has finished). */
 int32_t cpf_plan_last_kernel_ms(cpf_plan* plan, float* out_ms);
-/* Which kernel the last launch on this plan used: "layered/aot waves=1", "layered/jit waves=N" (runtime-specialised,
- * built on first use) or "generic/aot waves=N (reason)". */
+/* Which kernel the last launch on this plan used: "split/aot ...", "layered/aot waves=N", "dense/aot waves=N",
+ * "layered/jit(hipcc) waves=N" / "(hiprtc)" (runtime-specialised: the compiler that produced the code object, whether
+ * it was built in this process or came from a cache) or "generic/aot waves=N (reason)". */
 int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
+
+/* ---- runtime specialisation (no counterpart in the reference: jax.jit compiles on first call, optimization.py:361-363).
+ * cpf_jit_compiles: how many code objects this process has compiled so far (0 on a box that runs from ahead-of-time
+ * kernels and caches; CPF_JIT_FORBID_COMPILE=1 makes a needed compile an error instead).
+ * cpf_jit_precompile: build, WITHOUT a GPU, every runtime-specialised kernel a launch of `problem` with num_samples
+ * samples would try, into $CPF_JIT_CACHE (python -m cpflow_amd.build --precompile points it at the shipped
+ * <library dir>/jit_cache).  Returns the number of kernels (>= 0; 0 = the shape runs on ahead-of-time kernels only) and
+ * one line per kernel in buf, or a negative error code. */
+int32_t cpf_jit_compiles(void);
+int32_t cpf_jit_precompile(const cpf_problem* problem, int64_t num_samples, char* buf, size_t size);
 
 /* ---- host-pointer convenience (what a ctypes binding of _generate_raw + _evaluate_raw
  *      uses when the caller holds numpy memory): allocates device scratch, copies, runs,

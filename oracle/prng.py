@@ -71,20 +71,50 @@ def uniform(key, n, minval=0.0, maxval=2 * np.pi):
     return np.maximum(lo, f * (hi - lo) + lo).astype(np.float32)
 
 
-def initial_angles(seed, num_samples, num_angles, cp_mask=None, cp_dist='uniform'):
-    """Synthesize._generate_initial_angles (main.py:541-548) for 'uniform' / '0'.
+def erfinv_f32(x):
+    """lax.erf_inv in float32 as XLA lowers it (xla/client/lib/math.cc ErfInv32, Giles' single-precision polynomial in
+    w = -log((1 - x)(1 + x))).  Third-party arithmetic, restated from the published algorithm; PARITY UNPINNED: no result
+    file of the reference uses cp_distribution='normal'."""
+    f = np.float32
+    x = np.asarray(x, dtype=f)
+    w = -np.log1p(-x * x).astype(f)
+    lt = w < f(5)
+    w = np.where(lt, w - f(2.5), np.sqrt(w, dtype=f) - f(3)).astype(f)
+    ca = [2.81022636e-08, 3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087, -0.00125372503, -0.00417768164,
+          0.246640727, 1.50140941]
+    cb = [-0.000200214257, 0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773, -0.0076224613, 0.00943887047,
+          1.00167406, 2.83297682]
+    p = np.where(lt, f(ca[0]), f(cb[0])).astype(f)
+    for a, b in zip(ca[1:], cb[1:]):
+        p = (np.where(lt, f(a), f(b)) + p * w).astype(f)
+    return (p * x).astype(f)
 
-    keys = split(PRNGKey(seed), S+1)[1:]; per sample random_cp_angles does
-    key, subkey = split(k); angles = uniform(subkey, P) * (1 - mask if '0').
+
+def normal(key, n):
+    """random.normal(key, (n,), float32) of jax 0.3.x (_normal_real): sqrt(2) * erf_inv(uniform(key, nextafter(-1, 0), 1))."""
+    lo = np.nextafter(np.float32(-1), np.float32(0))
+    return (np.float32(np.sqrt(2)) * erfinv_f32(uniform(key, n, lo, np.float32(1)))).astype(np.float32)
+
+
+def initial_angles(seed, num_samples, num_angles, cp_mask=None, cp_dist='uniform'):
+    """Synthesize._generate_initial_angles (main.py:541-548).
+
+    keys = split(PRNGKey(seed), S+1)[1:]; per sample random_cp_angles (cp_utils.py:31-40) does
+    key, subkey = split(k); angles = uniform(subkey, P); '0': * (1 - mask); 'normal': key, subkey = split(key) again and
+    angles * (1 - mask) + 1.5 * normal(subkey, P) * mask.
     """
     keys = split(prng_key(seed), num_samples + 1)[1:]
     out = np.empty((num_samples, num_angles), dtype=np.float32)
+    mask = None if cp_mask is None else np.asarray(cp_mask, dtype=np.float32)
     for j, k in enumerate(keys):
-        sub = split(k, 2)[1]
+        key, sub = split(k, 2)
         out[j] = uniform(sub, num_angles)
+        if cp_dist == 'normal':
+            sub2 = split(key, 2)[1]
+            out[j] = out[j] * (1 - mask) + np.float32(1.5) * normal(sub2, num_angles) * mask
     if cp_dist == '0':
-        out = out * (1 - np.asarray(cp_mask, dtype=np.float32))
-    elif cp_dist != 'uniform':
+        out = out * (1 - mask)
+    elif cp_dist not in ('uniform', 'normal'):
         raise NotImplementedError(cp_dist)
     return out
 

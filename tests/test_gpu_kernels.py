@@ -72,6 +72,19 @@ def test_initial_angles_bit_exact():
         assert (part.view(np.uint32) == ref[S // 3:S // 3 + S // 2].view(np.uint32)).all()
     z = eng.initial_angles(5, 7, cp_dist='0').cpu().numpy()
     assert (z[:, eng.cp_mask == 1] == 0).all() and (z[:, eng.cp_mask == 0] != 0).any()
+    # cp_distribution='normal' (cp_utils.py:38-40): rotation angles as before (bit for bit), CP angles 1.5 * jax.random.normal
+    # from a second split of the sample key.  Parity unpinned (no reference result uses it): the device follows the NumPy
+    # restatement of jax's formula to float32 rounding of log1p / the polynomial, and the draws have the right moments.
+    for seed, S in [(3, 64), (1542702538, 4000)]:
+        ref = oracle.prng.initial_angles(seed, S, eng.num_angles, eng.cp_mask, 'normal')
+        got = eng.initial_angles(seed, S, cp_dist='normal').cpu().numpy()
+        plain = oracle.prng.initial_angles(seed, S, eng.num_angles)
+        assert (got[:, eng.cp_mask == 0].view(np.uint32) == plain[:, eng.cp_mask == 0].view(np.uint32)).all()
+        assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+        part = eng.initial_angles(seed, S, first=5, count=20, cp_dist='normal').cpu().numpy()
+        assert (part == got[5:25]).all()
+    cp = got[:, eng.cp_mask == 1]
+    assert abs(cp.mean()) < 0.03 and abs(cp.std() - 1.5) < 0.03 and abs((np.abs(cp) < 1.5).mean() - 0.6827) < 0.01
 
 
 @pytest.mark.parametrize('layer,K,rot', CASES[:3] + CASES[4:5] + CASES[6:7] + CASES[8:9])
@@ -202,8 +215,8 @@ def test_abi_errors_on_device():
     eng = TemplateEngine([[0, 1]], 2, np.eye(4))
     with pytest.raises(AssertionError):
         eng.optimize(np.zeros((2, eng.num_angles + 1), dtype=np.float32))
-    with pytest.raises(NotImplementedError):
-        eng.initial_angles(0, 4, cp_dist='normal')
+    with pytest.raises(ValueError, match='not supported'):
+        eng.initial_angles(0, 4, cp_dist='gauss')
 
 
 @pytest.mark.parametrize('loss,kind', [('state', 1), ('relative_phase', 2)])
@@ -374,3 +387,22 @@ def test_issue_priority_does_not_change_results(monkeypatch):
         res[prio] = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
     for k in res['0']:
         assert np.array_equal(res['0'][k], res['1'][k]), k
+
+
+def test_shipped_jit_cache_needs_no_compiler(monkeypatch):
+    """The reference's tutorial shape that has no ahead-of-time kernel (4-qubit star, tutorial/results/toff4_star) runs
+    from the code objects `python -m cpflow_amd.build --precompile` shipped in cpflow_amd/jit_cache: with run-time
+    compilation forbidden the launch still uses the specialised kernel built by hipcc, and this process compiles nothing."""
+    from cpflow_amd import _ffi
+    monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
+    layer, target = [[0, 1], [0, 2], [0, 3]], _rand_unitary(4, 2)
+    before = _ffi.lib().cpf_jit_compiles()
+    for K, S in ((23, 500), (29, 2048), (14, 40)):
+        eng = _engine(layer, K, target, 'xyz', num_gd_iterations=5)
+        eng.optimize(eng.initial_angles(1, S))
+        assert eng.last_variant().split(' ')[0] in ('layered/jit(hipcc)', 'dense/jit(hipcc)'), eng.last_variant()
+    assert _ffi.lib().cpf_jit_compiles() == before
+    # a shape nobody shipped fails loudly instead of compiling
+    eng = _engine([[3, 1], [0, 2], [2, 3], [1, 0]], 9, target, 'yx', num_gd_iterations=2)
+    with pytest.raises(ValueError, match='CPF_JIT_FORBID_COMPILE'):
+        eng.optimize(eng.initial_angles(1, 8))

@@ -158,3 +158,28 @@ def test_results_roundtrip(tmp_path):
     back = cpflow_amd.Results.load(str(tmp_path / 'r' / 'id'))
     assert repr(back.decompositions[0]) == repr(d) and back.layer == [[0, 1]]
     assert back.decompositions[0].loss < 1e-12
+
+
+def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
+    """Runtime specialisation without a GPU (hipcc cross-compiles): cpf_jit_precompile builds the kernels a launch of
+    the shape would try into $CPF_JIT_CACHE, a second call finds them there, and CPF_JIT_FORBID_COMPILE=1 turns a
+    needed compile into an error that names the switch."""
+    import subprocess
+    import sys
+    code = ("import json, sys; from cpflow_amd.build import _precompile_one; "
+            "print(json.dumps(_precompile_one([[2, 0], [1, 2]], 'yz', 5, 64)))")
+
+    def run(extra):
+        env = dict(os.environ, CPF_JIT_CACHE=str(tmp_path / 'cache'), **extra)
+        return subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=ROOT)
+    r = run({'CPF_JIT_FORBID_COMPILE': '1'})
+    assert r.returncode != 0 and 'CPF_JIT_FORBID_COMPILE' in r.stderr
+    r = run({})
+    assert r.returncode == 0, r.stderr
+    import json
+    lines = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(lines) == 2 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
+    assert lines[0].startswith('split/jit(hipcc) waves=2') and lines[1].startswith('layered/jit(hipcc) waves=1')
+    assert (os.stat(tmp_path / 'cache').st_mode & 0o077) == 0          # private directory
+    r = run({'CPF_JIT_FORBID_COMPILE': '1'})                           # now served from the cache
+    assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))

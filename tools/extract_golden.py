@@ -204,6 +204,24 @@ def extract_local_minimums():
         for rec in lst:
             rows.append((fn, str(rec.get('target_type')), int(rec.get('random_seed', -1)),
                          int(rec['num_cz_gates']), int(rec['num_qubits']), float(rec['success_ratio'])))
+    # the targets themselves for a subset (3 qubits, instances rs0 / rs1, 3..8 CZ gates), so that the success ratios can
+    # be re-measured on the same matrices (tests/test_gpu_baseline_configs.py::test_local_minimums_success_ratios)
+    sub = []
+    for fn in sorted(os.listdir(d)):
+        if not (fn.startswith('3q_') and fn.endswith(('rs0', 'rs1'))):
+            continue
+        with open(os.path.join(d, fn), 'rb') as f:
+            lst = NumpyOnly(f).load()
+        for rec in lst:
+            if 3 <= int(rec['num_cz_gates']) <= 8:
+                sub.append((fn, str(rec['target_type']), int(rec['num_cz_gates']), np.asarray(rec['u_target'], dtype=np.complex64),
+                            float(rec['success_ratio']), len(rec['losses']), float(np.min(rec['losses']))))
+    np.savez_compressed(
+        os.path.join(OUT, 'local_minimums_targets.npz'), source_file=np.array([r[0] for r in sub]),
+        target_type=np.array([r[1] for r in sub]), num_cz_gates=np.array([r[2] for r in sub], dtype=np.int32),
+        u_target=np.stack([r[3] for r in sub]), success_ratio=np.array([r[4] for r in sub]),
+        num_repeats=np.array([r[5] for r in sub], dtype=np.int32), min_loss=np.array([r[6] for r in sub], dtype=np.float32))
+    print(f'local_minimums_targets.npz: {len(sub)} records')
     out = os.path.join(OUT, 'local_minimums_summary.npz')
     np.savez_compressed(
         out, source_file=np.array([r[0] for r in rows]), target_type=np.array([r[1] for r in rows]),
