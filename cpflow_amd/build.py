@@ -56,6 +56,14 @@ def precompile(shapes=None, workers=None, verbose=True):
     build()
     os.makedirs(JIT_DIR, exist_ok=True)
     os.chmod(JIT_DIR, 0o700)
+    # code objects are keyed by a hash of the kernel headers: after a header edit every shipped object is stale
+    stamp, tag = os.path.join(JIT_DIR, '.stamp'), str(max(os.path.getmtime(d) for d in DEPS if d.endswith('.h')))
+    if not os.path.exists(stamp) or open(stamp).read() != tag:
+        for f in os.listdir(JIT_DIR):
+            if f.endswith('.hsaco') or '.tmp' in f:
+                os.unlink(os.path.join(JIT_DIR, f))
+        with open(stamp, 'w') as f:
+            f.write(tag)
     shapes = precompile_shapes() if shapes is None else shapes
     env = dict(os.environ, CPF_JIT_CACHE=JIT_DIR)
 

@@ -1,0 +1,595 @@
+// cpflow_amd: the dense-block kernel for 4..6 qubits — every entangling block is ONE 4x4 complex matrix applied to a
+// register-resident qubit pair.
+//
+// Why.  The gate-by-gate kernels (cpf_layered.h) are bound by VALU issue at the instruction count of their formulation:
+// a block is a CP and 2 x (1..3) rotations, each touching every amplitude (2 packed operations per amplitude for a
+// rotation on a register bit, 3 with a DPP partner fetch on a lane bit), three times per optimiser step (psi forward,
+// psi and C backward) plus one dot product per angle: ~47 packed operations per amplitude per block.  Here a block is
+//     forward     psi <- G psi                                   4 complex multiply-adds = 8 operations per amplitude
+//     backward    psi <- G^+ psi;  M += conj(C) (x) psi;  C <- G^+ C           3 x 8 operations per amplitude
+// i.e. 32, whatever the rotation string, and the block's angles are differentiated afterwards from the 4x4 environment
+// M by a miniature adjoint sweep (cpf_dense_math.h) - one thread per block, outside the sweeps.
+//
+// Layout.  Columns never interact: column bits -> wave bits (LW of them), then lane bits 0 .. NLC-1.  Row bits: the
+// remaining NLR = 6 - NLC lane bits are the TOP lane bits (4 and / or 5), every other row bit is a register bit, so a
+// thread holds E = 2^NRR complex amplitudes of psi (and of C) as (re, im) register pairs.  Row qubit q sits at canonical
+// position q: positions 0 .. NRR-1 are register bits, the last NLR qubits sit on the lanes.  A block whose pair
+// involves a lane qubit first exchanges that qubit with a register qubit outside the pair - v_permlane32_swap /
+// v_permlane16_swap move lane bit 5 / 4 against a register bit in ONE instruction per register pair, E per matrix -
+// and exchanges it back afterwards, so that between blocks the layout is always the canonical one.  No DPP, no LDS
+// traffic inside a sweep except the 128-byte G of each block (uniform address, broadcast reads).
+//
+// One kernel per (qubits, waves per sample) serves every layer, rotation string and entangler: which register bits a
+// block acts on and which exchanges it needs come from a per-block table the host builds (cpf_dense_block), dispatched
+// with scalar branches (one per ~10^3 vector instructions).
+//
+// Phases of one optimiser step (T of them in one launch, one workgroup per sample):
+//   owner    Adam on the angles this thread owns, their (cos, sin) to the gate records        [LDS: th, m, v, rec]
+//   build    thread b builds G_b from the records of block b                                   [LDS: Gm]
+//   forward  psi = I; surface gates (gate by gate, on register bits); blocks b = 0 .. K-1
+//   loss     T = sum conj(V) psi over the workgroup; best-iterate tracking
+//   backward C = f V; blocks K-1 .. 0 (fused pass above, M reduced over the wave -> LDS env); surface gates
+//   chain    thread b: angle gradients of block b from M_b (summed over waves) and G_b          [LDS: gw]
+#pragma once
+#include "cpf_blocks.h"
+#include "cpf_dense_math.h"
+
+namespace cpf {
+
+// what the host tells the kernel about block b (int4 per block)
+//   x, y : up to two lane<->register exchanges, each (lane_bit << 8) | reg_bit, or -1
+//   z    : (ra | rb << 4) with ra < rb the register bits the 4x4 acts on, | 256 if the placement's first qubit sits at ra
+//          (the lower bit; the block matrix is then built with its index bits exchanged)
+//   w    : index of the block's first gate (the entangler) in the gate program
+struct DenseBlock { int x, y, z, w; };
+
+template <int NQ_, int LW_>
+struct DLay {
+    static constexpr int NQ = NQ_, LW = LW_;
+    static constexpr int WPS = 1 << LW, THREADS = 64 * WPS, D = 1 << NQ;
+    static constexpr int NLC = NQ - LW;                 // column bits on lanes: lane bits 0 .. NLC-1
+    static constexpr int NLR = 6 - NLC;                 // row bits on lanes: lane bits NLC .. 5
+    static constexpr int NRR = NQ - NLR;                // row bits in registers
+    static constexpr int E = 1 << NRR;
+    static_assert(NLC >= 4 && NLC <= 6 && NRR >= 2, "dense layout: row lane bits must be lane bits 4 / 5, a block needs two register bits");
+    // canonical position of row qubit q: register bit NRR-1-q for q < NRR (qubit 0 = most significant), else lane bit NLC + (q - NRR)
+    __host__ __device__ static constexpr bool on_lane(int q) { return q >= NRR; }
+    __host__ __device__ static constexpr int reg_bit(int q) { return NRR - 1 - q; }
+    __host__ __device__ static constexpr int lane_bit(int q) { return NLC + (q - NRR); }
+    __device__ static int row_index(int lane, int e) {
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int b = on_lane(q) ? ((lane >> lane_bit(q)) & 1) : ((e >> reg_bit(q)) & 1);
+            r |= b << (NQ - 1 - q);
+        }
+        return r;
+    }
+    __device__ static int col_index(int lane, int wave) {      // column bits: wave bits first (most significant), then lane bits
+        return (wave << NLC) | (lane & ((1 << NLC) - 1));
+    }
+};
+
+// ---- host side: the per-block table ----------------------------------------------------------------------------
+// up, dn: the placement (up = first qubit).  Lane qubits of the pair are exchanged with the lowest register qubits
+// outside the pair.
+template <class L>
+inline DenseBlock dense_block_entry(int up, int dn, int first_gate) {
+    DenseBlock d{-1, -1, 0, first_gate};
+    int pos_up = L::on_lane(up) ? -1 : L::reg_bit(up), pos_dn = L::on_lane(dn) ? -1 : L::reg_bit(dn);
+    int next_q = 0, nswap = 0;
+    for (int which = 0; which < 2; which++) {
+        const int q = which == 0 ? up : dn;
+        if (!L::on_lane(q)) continue;
+        while (next_q == up || next_q == dn || L::on_lane(next_q)) next_q++;       // a register qubit outside the pair
+        const int rb = L::reg_bit(next_q++);
+        (nswap == 0 ? d.x : d.y) = (L::lane_bit(q) << 8) | rb;
+        nswap++;
+        (which == 0 ? pos_up : pos_dn) = rb;
+    }
+    const int ra = pos_up < pos_dn ? pos_up : pos_dn, rb = pos_up < pos_dn ? pos_dn : pos_up;
+    d.z = ra | (rb << 4) | (pos_up == ra ? 256 : 0);
+    return d;
+}
+
+// ---- packed complex helpers --------------------------------------------------------------------------------------
+// acc += a * b / conj(a) * b with a, b (re, im) pairs: two v_pk_fma_f32 (the swaps and signs are op_sel / neg bits)
+__device__ __forceinline__ f2 cmac(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.y), f2{-b.y, b.x}, pk_fma(splat(a.x), b, acc)); }
+__device__ __forceinline__ f2 cmac_conj(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.y), f2{b.y, -b.x}, pk_fma(splat(a.x), b, acc)); }
+__device__ __forceinline__ f2 cmul0(f2 a, f2 b) { return pk_fma(splat(a.y), f2{-b.y, b.x}, splat(a.x) * b); }
+__device__ __forceinline__ f2 cmul0_conj(f2 a, f2 b) { return pk_fma(splat(a.y), f2{b.y, -b.x}, splat(a.x) * b); }
+
+// exchange lane bit LB (4 or 5) with register bit RB of a matrix: one v_permlane{16,32}_swap per 32-bit register pair
+template <int E, int LB, int RB>
+__device__ __forceinline__ void swap_lane_reg(f2 (&x)[E]) {
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0++) {
+        if (e0 & (1 << RB)) continue;
+        const int e1 = e0 | (1 << RB);
+        // vdst = the register-bit-0 element, src = the register-bit-1 element: lanes with the lane bit set of vdst trade
+        // places with lanes with the lane bit clear of src
+        const f2 a = x[e0], b = x[e1];
+        if constexpr (LB == 5) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+            x[e0] = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+            x[e1] = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+        } else {
+            const auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+            const auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+            x[e0] = f2{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+            x[e1] = f2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+        }
+    }
+}
+template <class L>
+__device__ __forceinline__ void do_swap(f2 (&x)[L::E], int code) {
+    if (code < 0) return;
+    const int lb = code >> 8, rb = code & 255;
+#define CPF_SW(LBV, RBV) if constexpr ((LBV) >= L::NLC && (RBV) < L::NRR) { if (lb == (LBV) && rb == (RBV)) { swap_lane_reg<L::E, LBV, RBV>(x); return; } }
+    CPF_SW(5, 0) CPF_SW(5, 1) CPF_SW(5, 2) CPF_SW(5, 3) CPF_SW(5, 4)
+    CPF_SW(4, 0) CPF_SW(4, 1) CPF_SW(4, 2) CPF_SW(4, 3) CPF_SW(4, 4)
+#undef CPF_SW
+}
+
+// ---- the 4x4 on register bits RA < RB (index = 2 * bit RB + bit RA ... see below) -------------------------------
+// g[4 i + j] = G_ij as (re, im).  Basis index of a group: (bit RB of e) * 2 + (bit RA of e): the HIGHER register bit is the
+// high index bit; the host / build phase arranges G accordingly (DenseBlock::z bit 8).
+template <int E, int RA, int RB, bool ADJ>
+__device__ __forceinline__ void dense_apply(f2 (&x)[E], const f2 (&g)[16]) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (e & ((1 << RA) | (1 << RB))) continue;
+        const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
+        const f2 in[4] = {x[idx[0]], x[idx[1]], x[idx[2]], x[idx[3]]};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f2 acc = ADJ ? cmul0_conj(g[i], in[0]) : cmul0(g[4 * i], in[0]);
+#pragma unroll
+            for (int j = 1; j < 4; j++) acc = ADJ ? cmac_conj(acc, g[4 * j + i], in[j]) : cmac(acc, g[4 * i + j], in[j]);
+            x[idx[i]] = acc;
+        }
+    }
+}
+// backward pass of one block, fused per group of four amplitudes:  psi <- G^+ psi,  M_ij += conj(C_i) psi_j,  C <- G^+ C
+template <int E, int RA, int RB>
+__device__ __forceinline__ void dense_backward(f2 (&p)[E], f2 (&c)[E], const f2 (&g)[16], f2 (&m)[16]) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (e & ((1 << RA) | (1 << RB))) continue;
+        const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
+        const f2 pin[4] = {p[idx[0]], p[idx[1]], p[idx[2]], p[idx[3]]};
+        const f2 cin[4] = {c[idx[0]], c[idx[1]], c[idx[2]], c[idx[3]]};
+        f2 pq[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f2 acc = cmul0_conj(g[i], pin[0]);
+#pragma unroll
+            for (int j = 1; j < 4; j++) acc = cmac_conj(acc, g[4 * j + i], pin[j]);
+            pq[i] = acc;
+            p[idx[i]] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_conj(m[4 * i + j], cin[i], pq[j]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f2 acc = cmul0_conj(g[i], cin[0]);
+#pragma unroll
+            for (int j = 1; j < 4; j++) acc = cmac_conj(acc, g[4 * j + i], cin[j]);
+            c[idx[i]] = acc;
+        }
+    }
+}
+
+#define CPF_PAIR_SWITCH(PAIR, BODY)                                                                   \
+    switch (PAIR) {                                                                                   \
+        case 0x10: { constexpr int RA = 0, RB = 1; BODY; } break;                                     \
+        case 0x20: if constexpr (L::NRR > 2) { constexpr int RA = 0, RB = 2; BODY; } break;           \
+        case 0x21: if constexpr (L::NRR > 2) { constexpr int RA = 1, RB = 2; BODY; } break;           \
+        case 0x30: if constexpr (L::NRR > 3) { constexpr int RA = 0, RB = 3; BODY; } break;           \
+        case 0x31: if constexpr (L::NRR > 3) { constexpr int RA = 1, RB = 3; BODY; } break;           \
+        case 0x32: if constexpr (L::NRR > 3) { constexpr int RA = 2, RB = 3; BODY; } break;           \
+        case 0x40: if constexpr (L::NRR > 4) { constexpr int RA = 0, RB = 4; BODY; } break;           \
+        case 0x41: if constexpr (L::NRR > 4) { constexpr int RA = 1, RB = 4; BODY; } break;           \
+        case 0x42: if constexpr (L::NRR > 4) { constexpr int RA = 2, RB = 4; BODY; } break;           \
+        case 0x43: if constexpr (L::NRR > 4) { constexpr int RA = 3, RB = 4; BODY; } break;           \
+        default: break;                                                                               \
+    }
+
+// ---- rotations on a register bit (surface gates; the register branch of cpf_device.h rot_apply / rot_grad) --------
+template <int E, int KIND, int BIT>
+__device__ __forceinline__ void rot_reg(f2 (&x)[E], float c, float s) {
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0++) {
+        if (e0 & (1 << BIT)) continue;
+        const int e1 = e0 | (1 << BIT);
+        const f2 a = x[e0], b = x[e1];
+        if constexpr (KIND == OP_RX) {            // a' = c a - i s b, b' = c b - i s a
+            x[e0] = pk_fma(f2{s, -s}, swp(b), splat(c) * a);
+            x[e1] = pk_fma(f2{s, -s}, swp(a), splat(c) * b);
+        } else {                                  // Rz: a' = (c - i s) a, b' = (c + i s) b
+            x[e0] = pk_fma(f2{s, -s}, swp(a), splat(c) * a);
+            x[e1] = pk_fma(f2{-s, s}, swp(b), splat(c) * b);
+        }
+    }
+}
+// this thread's share of sum Im(conj(C) sigma psi), psi and C right after the gate
+template <int E, int KIND, int BIT>
+__device__ __forceinline__ float rot_reg_grad(const f2 (&p)[E], const f2 (&c)[E]) {
+    f2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0++) {
+        if (e0 & (1 << BIT)) continue;
+        const int e1 = e0 | (1 << BIT);
+        if constexpr (KIND == OP_RX) { acc = pk_fma(c[e0], swp(p[e1]), acc); acc = pk_fma(c[e1], swp(p[e0]), acc); }
+        else { acc = pk_fma(c[e0], swp(p[e0]), acc); acc = pk_fma(-c[e1], swp(p[e1]), acc); }
+    }
+    return acc.x - acc.y;
+}
+#define CPF_BIT_SWITCH(BITV, BODY)                                                        \
+    switch (BITV) {                                                                       \
+        case 0: { constexpr int BIT = 0; BODY; } break;                                   \
+        case 1: { constexpr int BIT = 1; BODY; } break;                                   \
+        case 2: if constexpr (L::NRR > 2) { constexpr int BIT = 2; BODY; } break;         \
+        case 3: if constexpr (L::NRR > 3) { constexpr int BIT = 3; BODY; } break;         \
+        case 4: if constexpr (L::NRR > 4) { constexpr int BIT = 4; BODY; } break;         \
+        default: break;                                                                   \
+    }
+
+// ---- reduction of the 16 complex environment partials over the wave ------------------------------------------------
+// 32 per-lane values -> value v summed over all 64 lanes, left in LDS dst[v].  Lane bits 5 and 4 by permlane swaps (one
+// swap + one add settle TWO values), then the 8-value DPP reduce-scatter of cpf_blocks.h over bits 2, 3, 0, 1.
+// dst_of_lane: where this lane's final value goes (dense_env_dst).
+__device__ __forceinline__ int dense_env_dst(int lane) {
+    // after the bit-5 stage register r holds value 2 r + (lane bit 5); after the bit-4 stage register r holds value
+    // 4 r + 2 (lane bit 4) + (lane bit 5) of the previous numbering; reduce8 then leaves value index k = reduce8 slot
+    const int k = 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);     // register index r (0..7) this lane ends with
+    return 4 * k + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+}
+__device__ __forceinline__ void dense_env_reduce(const f2 (&m)[16], float* dst, int lane, int dst_lane) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { v[2 * i] = m[i].x; v[2 * i + 1] = m[i].y; }
+    float w[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {                       // bit 5: values 2r (kept by the low half), 2r + 1 (high half)
+        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * r]), __float_as_uint(v[2 * r + 1]), false, false);
+        w[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+    float u[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {                        // bit 4
+        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r]), __float_as_uint(w[2 * r + 1]), false, false);
+        u[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+    // bits 2, 3 (reduce-scatter 8 -> 2), bit 0 (2 -> 1), bit 1 (sum): as reduce8_rows, but the 16-lane rows already hold
+    // different values, so every lane's result is final: one store per lane (lanes l and l ^ 2 store the same word)
+    float e0, e1, e2, e3, f0, f1;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(f0), "=&v"(f1)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]));
+    const bool b0 = lane & 1;
+    const float keep = b0 ? f1 : f0, give = b0 ? f0 : f1;
+    float r = keep + dppz<0xB1>(give);
+    r += dppz<0x4E>(r);
+    dst[dst_lane] = r;
+}
+
+// ---- LDS map (float offsets) -------------------------------------------------------------------------------------------
+struct DenseLds {
+    int rec, gm, th, mm, vv, psl, gw, env, gsurf, red, total;
+    __host__ __device__ DenseLds(int P, int G, int K, int nq, int wps) {
+        rec = PEN_FLOATS;                      // G x {cos, sin, code, -}
+        gm = rec + 4 * G;                      // K x 16 x (re, im): the block matrices
+        th = gm + 32 * K;                      // owner state and r * penalty slope, P each
+        mm = th + P; vv = mm + P; psl = vv + P;
+        gw = psl + P;                          // G: gradient of each gate's angle
+        env = gw + G;                          // [wps][K][32]: environments, reduced over the wave
+        gsurf = env + wps * K * 32;            // [wps][NBATCH][32]: surface-gate gradient partials (reduce8_rows slabs)
+        red = gsurf + wps * ((3 * nq + 7) / 8) * 32;
+        total = red + 8 * wps + 4;
+        total = (total + 3) & ~3;
+    }
+};
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------
+struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot; };
+
+template <int NQ, int LW>
+__global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
+    using L = DLay<NQ, LW>;
+    constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
+    const KArgs& a = da.k;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = a.P, G = a.G, K = da.K, NR = da.n_rot;
+    const DenseLds lds(P, G, K, NQ, WPS);
+    float4* rec = reinterpret_cast<float4*>(smem + lds.rec);
+    float* th = smem + lds.th;
+    float* mm = smem + lds.mm;
+    float* vv = smem + lds.vv;
+    float* psl = smem + lds.psl;
+    float* gw = smem + lds.gw;
+    float* red = smem + lds.red;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t s_idx = blockIdx.x;
+    const float* init = a.init + s_idx * P;
+    const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
+    const int col = L::col_index(lane, wave);
+    const int env_dst = dense_env_dst(lane), surf_dst = reduce8_dst_lane(lane);
+    float* env_w = smem + lds.env + wave * K * 32;
+    float* gsurf_w = smem + lds.gsurf + wave * NBATCH * 32;
+    const_i_ptr blk = (const_i_ptr)(const int*)da.blocks;          // scalar loads: the table is wave-uniform
+
+    penalty_table_init(smem, a, tid);
+    for (int g = tid; g < G; g += THREADS) {
+        const int4 op = a.prog[g];
+        rec[g] = make_float4(op.x == OP_CZ ? -1.f : 1.f, 0.f, __int_as_float(op.x | (op.y << 4) | (op.z << 8)), 0.f);
+    }
+    lds_sync<WPS>();
+    auto publish = [&](int j, float t) {
+        float sn, cn;
+        const bool cp = a.pkind[j];
+        fast_sincos(cp ? t : 0.5f * t, sn, cn);
+        *reinterpret_cast<float2*>(&rec[a.pgate[j]]) = make_float2(cn, sn);
+    };
+    for (int j = tid; j < P; j += THREADS) {
+        const float t0 = init[j];
+        th[j] = t0; mm[j] = 0.f; vv[j] = 0.f;
+        a.out_params[(s_idx * 2 + 0) * P + j] = t0;
+        a.out_params[(s_idx * 2 + 1) * P + j] = t0;
+        publish(j, t0);
+    }
+    lds_sync<WPS>();
+
+    // record fetch of block b for cpf_dense_math.h: gate g0 + i
+    auto block_rec = [&](int g0) {
+        return [rec, g0](int i, float& c, float& s, int& kind) {
+            const float4 r = rec[g0 + i];
+            c = r.x; s = r.y; kind = __float_as_int(r.z) & 15;
+        };
+    };
+
+    f2 psi[E], cot[E];
+    float best = 0.f, first = 0.f;
+    const int iters = a.T > 0 ? a.T : 1;
+    for (int it = 0; it < iters; it++) {
+        const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
+        // ================= build: G_b from the gate records, one thread per block
+        for (int b = tid; b < K; b += THREADS) {
+            const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
+            dense::cx Gb[4][4];
+            dense::block_matrix(Gb, block_rec(g0), NR);
+            const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
+            float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const dense::cx v = Gb[i][j];
+                    const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
+                    out[4 * ii + jj] = make_float2(v.re, v.im);
+                }
+        }
+        lds_sync<WPS>();
+
+        // ================= forward
+#pragma unroll
+        for (int e = 0; e < E; e++) psi[e] = f2{(L::row_index(lane, e) == col) ? 1.f : 0.f, 0.f};
+        for (int q = 0; q < NQ; q++) {                     // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
+            const float4 r0 = rec[3 * q], r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
+            // a lane qubit borrows register bit 0 (qubit NRR-1) for its three gates
+            const int sw = L::on_lane(q) ? ((L::lane_bit(q) << 8) | 0) : -1, bit = L::on_lane(q) ? 0 : L::reg_bit(q);
+            do_swap<L>(psi, sw);
+            CPF_BIT_SWITCH(bit, (rot_reg<E, OP_RZ, BIT>(psi, r0.x, r0.y), rot_reg<E, OP_RX, BIT>(psi, r1.x, r1.y), rot_reg<E, OP_RZ, BIT>(psi, r2.x, r2.y)));
+            do_swap<L>(psi, sw);
+        }
+        for (int b = 0; b < K; b++) {
+            const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
+            f2 g[16];
+            const float4* gp = reinterpret_cast<const float4*>(smem + lds.gm + 32 * b);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
+            do_swap<L>(psi, sx);
+            do_swap<L>(psi, sy);
+            CPF_PAIR_SWITCH(pair, (dense_apply<E, RA, RB, false>(psi, g)));
+            do_swap<L>(psi, sy);
+            do_swap<L>(psi, sx);
+        }
+
+        // ================= loss (matrix_utils.py:35-42) and penalty (main.py:563-564)
+        float acc[3] = {0.f, 0.f, 0.f};
+        {
+            f2 tt = {0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float2 t = a.target[L::row_index(lane, e) * L::D + col];
+                if (a.loss_kind == 2) acc[0] = fmaf(fmaf(t.x, t.x, t.y * t.y), fmaf(psi[e].x, psi[e].x, psi[e].y * psi[e].y), acc[0]);
+                else { tt = pk_fma(splat(t.x), psi[e], tt); tt = pk_fma(f2{t.y, -t.y}, swp(psi[e]), tt); }
+            }
+            if (a.loss_kind != 2) { acc[0] = tt.x; acc[1] = tt.y; }
+        }
+        if (a.use_reg) {
+            for (int j = tid; j < P; j += THREADS) {
+                if (a.pkind[j]) {
+                    float sl;
+                    acc[2] += penalty_lds(smem, a.pen_kind, th[j], sl);
+                    psl[j] = a.r * sl;
+                }
+            }
+        }
+        {   // sum over the workgroup (fixed order: deterministic)
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+            if constexpr (WPS > 1) {
+                lds_sync<WPS>();
+                if (lane == 0) { red[wave * 3] = acc[0]; red[wave * 3 + 1] = acc[1]; red[wave * 3 + 2] = acc[2]; }
+                lds_sync<WPS>();
+#pragma unroll
+                for (int k = 0; k < 3; k++) { float s = 0.f; for (int w = 0; w < WPS; w++) s += red[w * 3 + k]; acc[k] = s; }
+            }
+        }
+        const float tr = acc[0], ti = acc[1];
+        const float ab = sqrtf(fmaf(tr, tr, ti * ti));
+        const float loss = (a.loss_kind == 2) ? 1.f - tr * a.inv_dim2 : 1.f - ab * ab * a.inv_dim2;
+        const float reg = a.use_reg ? a.r * acc[2] : 0.f;
+        const float regloss = loss + reg;
+        bool improved = false;
+        if (it == 0) { first = regloss; best = regloss; }
+        else if (regloss < best) { best = regloss; improved = true; }
+        if (improved || a.hist_params) {
+            for (int j = tid; j < P; j += THREADS) {
+                const float t = th[j];
+                if (improved) a.out_params[(s_idx * 2 + 1) * P + j] = t;
+                if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + j] = t;
+            }
+        }
+        if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
+        if (a.T == 0) break;
+
+        // ================= backward: C = (1/2) dL/dU* = f V (or -|V|^2 psi / D for the relative-phase loss)
+        {
+            const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float2 t = a.target[L::row_index(lane, e) * L::D + col];
+                if (a.loss_kind == 2) cot[e] = splat(-a.inv_dim2 * fmaf(t.x, t.x, t.y * t.y)) * psi[e];
+                else cot[e] = cmul(f2{t.x, t.y}, f2{fr, fi});
+            }
+        }
+        for (int b = K - 1; b >= 0; b--) {
+            const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
+            f2 g[16], m[16];
+            const float4* gp = reinterpret_cast<const float4*>(smem + lds.gm + 32 * b);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
+#pragma unroll
+            for (int i = 0; i < 16; i++) m[i] = f2{0.f, 0.f};
+            do_swap<L>(psi, sx); do_swap<L>(cot, sx);
+            do_swap<L>(psi, sy); do_swap<L>(cot, sy);
+            CPF_PAIR_SWITCH(pair, (dense_backward<E, RA, RB>(psi, cot, g, m)));
+            do_swap<L>(psi, sy); do_swap<L>(cot, sy);
+            do_swap<L>(psi, sx); do_swap<L>(cot, sx);
+            dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+        }
+        {   // surface gates, backwards: gradient right after each gate, then un-apply it from psi and C
+            float ds[8 * NBATCH];
+#pragma unroll
+            for (int k = 0; k < 8 * NBATCH; k++) ds[k] = 0.f;
+            for (int q = NQ - 1; q >= 0; q--) {
+                const float4 r0 = rec[3 * q], r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
+                const int sw = L::on_lane(q) ? ((L::lane_bit(q) << 8) | 0) : -1, bit = L::on_lane(q) ? 0 : L::reg_bit(q);
+                do_swap<L>(psi, sw); do_swap<L>(cot, sw);
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                CPF_BIT_SWITCH(bit, (d2 = rot_reg_grad<E, OP_RZ, BIT>(psi, cot), rot_reg<E, OP_RZ, BIT>(psi, r2.x, -r2.y), rot_reg<E, OP_RZ, BIT>(cot, r2.x, -r2.y),
+                                     d1 = rot_reg_grad<E, OP_RX, BIT>(psi, cot), rot_reg<E, OP_RX, BIT>(psi, r1.x, -r1.y), rot_reg<E, OP_RX, BIT>(cot, r1.x, -r1.y),
+                                     d0 = rot_reg_grad<E, OP_RZ, BIT>(psi, cot), rot_reg<E, OP_RZ, BIT>(psi, r0.x, -r0.y), rot_reg<E, OP_RZ, BIT>(cot, r0.x, -r0.y)));
+                do_swap<L>(psi, sw); do_swap<L>(cot, sw);
+                // static slots: q is a loop variable, ds a register array
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) if (qq == q) { ds[3 * qq] = d0; ds[3 * qq + 1] = d1; ds[3 * qq + 2] = d2; }
+            }
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; bt++) {
+                float d8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d8[k] = ds[8 * bt + k];
+                reduce8_rows(d8, gsurf_w + 32 * bt, lane, surf_dst);
+            }
+        }
+        lds_sync<WPS>();
+
+        // ================= chain: the angle gradients of block b from its environment; surface gradients
+        for (int b = tid; b < K; b += THREADS) {
+            const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
+            const bool up_low = (z & 256) != 0;
+            dense::cx Gb[4][4], Mb[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
+                    float2 mv = make_float2(0.f, 0.f);
+                    for (int w = 0; w < WPS; w++) {
+                        const float2 t = *reinterpret_cast<const float2*>(smem + lds.env + (w * K + b) * 32 + 2 * (4 * ii + jj));
+                        mv.x += t.x; mv.y += t.y;
+                    }
+                    Mb[i][j] = dense::mk(mv.x, mv.y);
+                    const float2 gv = *reinterpret_cast<const float2*>(smem + lds.gm + 32 * b + 2 * (4 * ii + jj));
+                    Gb[i][j] = dense::mk(gv.x, gv.y);
+                }
+            dense::block_gradient(gw + g0, Gb, Mb, block_rec(g0), NR);     // gate g0 + i carries angle i of the block
+        }
+        for (int g = tid; g < NS; g += THREADS) {
+            float s = 0.f;
+            for (int w = 0; w < WPS; w++) {
+                const float4 gp = *reinterpret_cast<const float4*>(smem + lds.gsurf + w * NBATCH * 32 + 32 * (g / 8) + 4 * (g % 8));
+                s += (gp.x + gp.y) + (gp.z + gp.w);
+            }
+            gw[g] = s;
+        }
+        lds_sync<WPS>();
+
+        // ================= Adam (optax 0.1.1 scale_by_adam + scale(-lr)), owners only
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
+        for (int j = tid; j < P; j += THREADS) {
+            float g = gw[a.pgate[j]];
+            if (a.use_reg && a.pkind[j]) g += psl[j];
+            if (frozen && frozen[j]) continue;
+            const float m = fmaf(a.b1, mm[j], a.omb1 * g);
+            const float v = fmaf(a.b2, vv[j], a.omb2 * (g * g));
+            mm[j] = m; vv[j] = v;
+            const float t = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[j]);
+            th[j] = t;
+            publish(j, t);
+        }
+        lds_sync<WPS>();
+    }
+
+    // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370); argmin, CZ count, entry-loss flag
+    const int bi = (best < first) ? 1 : 0;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = tid; j < P; j += THREADS) {
+        if (a.pkind[j]) {
+            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j];
+            const float t1 = a.out_params[(s_idx * 2 + 1) * P + j];
+            float sl;
+            if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
+            acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+    if constexpr (WPS > 1) {
+        lds_sync<WPS>();
+        if (lane == 0) { red[wave * 3] = acc[0]; red[wave * 3 + 1] = acc[1]; red[wave * 3 + 2] = acc[2]; }
+        lds_sync<WPS>();
+#pragma unroll
+        for (int k = 0; k < 3; k++) { float s = 0.f; for (int w = 0; w < WPS; w++) s += red[w * 3 + k]; acc[k] = s; }
+    }
+    if (tid == 0) {
+        const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
+        const float l0 = first - reg0, l1 = best - reg1;
+        a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
+        a.out_reg[s_idx * 2 + 0] = reg0;      a.out_reg[s_idx * 2 + 1] = reg1;
+        a.out_loss[s_idx * 2 + 0] = l0;       a.out_loss[s_idx * 2 + 1] = l1;
+        a.out_cz[s_idx] = (int32_t)acc[2];
+        a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
+    }
+}
+
+}  // namespace cpf

@@ -1,0 +1,166 @@
+// cpflow_amd: per-block 4x4 algebra of the dense-block kernel (cpf_dense.h), plain C++ so that the same code is
+// unit-tested on the CPU (tests/test_dense_math.py builds it with g++).
+//
+// One entangling block of the template (cpflow/main.py:69-82) acts on its qubit pair as the 4x4 matrix
+//     G = A_m ... A_2 A_1 E,     E = CP(a) | CZ | CX,   A_1 = R_g0(up), A_2 = R_g0(dn), A_3 = R_g1(up), ...
+// in the basis index 2 * up + dn (up = first qubit of the placement, gates.py / circuit_assembly.py:16-28).
+//   block_matrix      G from the block's (cos, sin) records                         [before the forward sweep]
+//   block_gradient    the block's angle gradients from the 4x4 environment
+//                         M_ij = sum_{other qubits, columns} conj(C_i) psi_j        [after the backward sweep]
+//                     where psi is the state before the block and C the loss cotangent after it:
+//                         dL = 2 Re sum_ij dG_ij M_ij   =>   dL/dtheta_k = Im tr(sigma_k R_k M^T L_k),
+//                     R_k = A_k .. A_1 E, L_k = A_m .. A_{k+1}: a miniature adjoint sweep over 4x4 matrices
+//                     (the same formula the gate-by-gate kernels evaluate on the full state, cpf_device.h rot_grad).
+#pragma once
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define CPF_HD __host__ __device__ __forceinline__
+#else
+#define CPF_HD inline
+#endif
+
+namespace cpf {
+namespace dense {
+
+enum : int { K_RX = 0, K_RY = 1, K_RZ = 2, K_CP = 3, K_CZ = 4, K_CX = 5 };     // = OP_* of cpf_device.h
+
+struct cx { float re, im; };
+CPF_HD cx mk(float re, float im) { cx r; r.re = re; r.im = im; return r; }
+CPF_HD cx cmulc(cx a, cx b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+
+// X <- R X (rows) for R = exp(-i a sigma / 2) on the up (bit 1) or dn (bit 0) index; (c, s) = (cos a/2, sin a/2);
+// s -> -s gives the inverse.  X[r][j], r = 2 up + dn.
+template <bool ON_UP>
+CPF_HD void rot_rows(cx (&X)[4][4], int kind, float c, float s) {
+    constexpr int b = ON_UP ? 2 : 1;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; r0++) {
+        if (r0 & b) continue;
+        const int r1 = r0 | b;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const cx x0 = X[r0][j], x1 = X[r1][j];
+            if (kind == K_RX) {            // [[c, -is], [-is, c]]
+                X[r0][j] = mk(c * x0.re + s * x1.im, c * x0.im - s * x1.re);
+                X[r1][j] = mk(c * x1.re + s * x0.im, c * x1.im - s * x0.re);
+            } else if (kind == K_RY) {     // [[c, -s], [s, c]]
+                X[r0][j] = mk(c * x0.re - s * x1.re, c * x0.im - s * x1.im);
+                X[r1][j] = mk(c * x1.re + s * x0.re, c * x1.im + s * x0.im);
+            } else {                       // diag(c - is, c + is)
+                X[r0][j] = mk(c * x0.re + s * x0.im, c * x0.im - s * x0.re);
+                X[r1][j] = mk(c * x1.re - s * x1.im, c * x1.im + s * x1.re);
+            }
+        }
+    }
+}
+// Z <- Z R (columns)
+template <bool ON_UP>
+CPF_HD void rot_cols(cx (&Z)[4][4], int kind, float c, float s) {
+    constexpr int b = ON_UP ? 2 : 1;
+#pragma unroll
+    for (int c0 = 0; c0 < 4; c0++) {
+        if (c0 & b) continue;
+        const int c1 = c0 | b;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const cx z0 = Z[i][c0], z1 = Z[i][c1];
+            if (kind == K_RX) {            // (Z R)[i][c0] = c z0 - i s z1, [i][c1] = -i s z0 + c z1
+                Z[i][c0] = mk(c * z0.re + s * z1.im, c * z0.im - s * z1.re);
+                Z[i][c1] = mk(c * z1.re + s * z0.im, c * z1.im - s * z0.re);
+            } else if (kind == K_RY) {     // [i][c0] = c z0 + s z1, [i][c1] = -s z0 + c z1
+                Z[i][c0] = mk(c * z0.re + s * z1.re, c * z0.im + s * z1.im);
+                Z[i][c1] = mk(c * z1.re - s * z0.re, c * z1.im - s * z0.im);
+            } else {
+                Z[i][c0] = mk(c * z0.re + s * z0.im, c * z0.im - s * z0.re);
+                Z[i][c1] = mk(c * z1.re - s * z1.im, c * z1.im + s * z1.re);
+            }
+        }
+    }
+}
+// Im tr(sigma X Z), sigma the Pauli matrix of `kind` on the up / dn index
+template <bool ON_UP>
+CPF_HD float im_trace_sigma(const cx (&X)[4][4], const cx (&Z)[4][4], int kind) {
+    constexpr int b = ON_UP ? 2 : 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool hi = (r & b) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const cx z = Z[j][r];
+            if (kind == K_RX) {            // (sigma X)[r] = X[r ^ b]
+                const cx x = X[r ^ b][j];
+                acc += x.re * z.im + x.im * z.re;
+            } else if (kind == K_RY) {     // (sigma X)[r] = -i X[r ^ b] (bit clear), +i X[r ^ b] (bit set)
+                const cx x = X[r ^ b][j];
+                const float im = x.re * z.re - x.im * z.im;      // Im(i x z) = Re(x z)
+                acc += hi ? im : -im;
+            } else {                       // (sigma X)[r] = +X[r] (bit clear), -X[r] (bit set)
+                const cx x = X[r][j];
+                const float im = x.re * z.im + x.im * z.re;
+                acc += hi ? -im : im;
+            }
+        }
+    }
+    return acc;
+}
+
+// Entangler as the starting matrix.  (cc, sc) = (cos a, sin a) of the CP angle (unused for CZ / CX).
+CPF_HD void entangler_matrix(cx (&X)[4][4], int ent, float cc, float sc) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) X[i][j] = mk(0.f, 0.f);
+    X[0][0] = mk(1.f, 0.f); X[1][1] = mk(1.f, 0.f);
+    // selects, not conditional stores (a store under a branch makes the compiler index the array dynamically -> scratch)
+    const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;       // CX: control = up, target = dn (gates.py:40-43)
+    X[2][2] = mk(is_cx ? 0.f : 1.f, 0.f); X[2][3] = mk(is_cx ? 1.f : 0.f, 0.f);
+    X[3][2] = mk(is_cx ? 1.f : 0.f, 0.f);
+    X[3][3] = mk(is_cx ? 0.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : sc);
+}
+
+// rec: the block's gate records in program order, 4 floats each {cos, sin, code, -} with code = kind | q0 << 4 | q1 << 8
+// (the generic kernel's LDS records): rec[0] the entangler, then R_g(up), R_g(dn) per rotation letter.
+// `read(g, &c, &s, &kind)` abstracts the record fetch so that device code reads LDS and the CPU test reads an array.
+template <class Rec>
+CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot) {
+    float c, s; int kind;
+    rec(0, c, s, kind);
+    entangler_matrix(G, kind, c, s);
+    for (int i = 0; i < n_rot; i++) {
+        rec(1 + 2 * i, c, s, kind);
+        rot_rows<true>(G, kind, c, s);
+        rec(2 + 2 * i, c, s, kind);
+        rot_rows<false>(G, kind, c, s);
+    }
+}
+// grad[0] = entangler angle (CP only, else 0), grad[1 + k] = rotation k in program order.  G = the block matrix.
+template <class Rec>
+CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot) {
+    cx X[4][4], Z[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { X[i][j] = G[i][j]; Z[i][j] = M[j][i]; }
+    float c, s; int kind;
+    for (int i = n_rot - 1; i >= 0; i--) {
+        rec(2 + 2 * i, c, s, kind);                       // R_i(dn), the later of the pair
+        grad[2 + 2 * i] = im_trace_sigma<false>(X, Z, kind);
+        rot_rows<false>(X, kind, c, -s);
+        rot_cols<false>(Z, kind, c, s);
+        rec(1 + 2 * i, c, s, kind);                       // R_i(up)
+        grad[1 + 2 * i] = im_trace_sigma<true>(X, Z, kind);
+        rot_rows<true>(X, kind, c, -s);
+        rot_cols<true>(Z, kind, c, s);
+    }
+    rec(0, c, s, kind);
+    // dE/da = i |11><11| E  ->  dL/da = 2 Re(i (E Z)[3][3]) = -2 Im(e^{ia} Z[3][3])
+    grad[0] = kind == K_CP ? -2.f * (c * Z[3][3].im + s * Z[3][3].re) : 0.f;
+}
+
+// When the placement's first qubit sits on the LOWER of the two register bits the kernel applies the block with the
+// roles of the index bits exchanged: G'[(i_d, i_u)][(j_d, j_u)] = G[(i_u, i_d)][(j_u, j_d)].
+CPF_HD int swap_bits2(int i) { return ((i & 1) << 1) | (i >> 1); }
+
+}  // namespace dense
+}  // namespace cpf

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,7 @@
 #include "cpf_blocks.h"
 #include "cpf_layered.h"
 #include "cpf_split.h"
+#include "cpf_dense.h"
 #include "cpf_jit.h"
 
 namespace {
@@ -53,6 +55,8 @@ struct cpf_plan {
     int entangler = 0;
     std::string rot;
     std::vector<int> layer_ud;       // (up, dn, up, dn, ...) of the shortest period of the placements
+    std::vector<int> h_place;        // (up, dn) of every block
+    std::map<int, DevBuf> dense_tab; // per waves-per-sample variant of the dense kernel: its per-block table (cpf_dense.h)
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
     std::string variant;             // kernel variant of the last launch
@@ -253,6 +257,45 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
     return false;
 }
 
+// ---- dense-block kernel (cpf_dense.h): 4..6 qubits, any layer / rotation string / entangler, no runtime compilation
+template <int NQ, int LW>
+int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+    using L = cpf::DLay<NQ, LW>;
+    DevBuf& tab = plan->dense_tab[LW];
+    const int K = plan->K, per_block = 1 + 2 * plan->n_rot;
+    if (!tab.p) {
+        std::vector<cpf::DenseBlock> h((size_t)K);
+        for (int b = 0; b < K; b++) h[b] = cpf::dense_block_entry<L>(plan->h_place[2 * b], plan->h_place[2 * b + 1], 3 * plan->n + per_block * b);
+        CPF_HIP(tab.alloc(h.size() * sizeof(cpf::DenseBlock)));
+        CPF_HIP(hipMemcpy(tab.p, h.data(), h.size() * sizeof(cpf::DenseBlock), hipMemcpyHostToDevice));
+    }
+    const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, K, NQ, L::WPS).total * sizeof(float);
+    if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
+    if (lds > 64 * 1024)
+        CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_dense<NQ, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), K, plan->n_rot};
+    hipLaunchKernelGGL((cpf::k_cp_dense<NQ, LW>), dim3((unsigned)S), dim3(L::THREADS), lds, stream, da);
+    CPF_HIP(hipGetLastError());
+    plan->variant = std::string("dense/aot waves=") + std::to_string(L::WPS);
+    return 0;
+}
+// 6 qubits: 2 waves per sample (32 amplitudes per thread), 4 on request; 5 qubits: 1 wave (16 per thread) while the samples
+// fill the SIMDs, else 2 (8 per thread); 4 qubits (4 per thread): the 32-value environment reduction costs as much as the
+// block there, so the gate-by-gate kernel stays the default (CPF_DENSE=1 selects the dense one).
+bool try_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
+    const char* e = getenv("CPF_DENSE");
+    if (e ? e[0] == '0' : plan->NQ == 4) return false;
+    const char* w = getenv("CPF_DENSE_LW");
+    const int64_t simds = (int64_t)plan->num_cu * 4;
+    switch (plan->NQ) {
+        case 6: *rc = (w && w[0] == '2') ? launch_dense<6, 2>(plan, a, S, stream) : launch_dense<6, 1>(plan, a, S, stream); return true;
+        case 5: *rc = (w ? w[0] == '1' : 2 * S < simds) ? launch_dense<5, 1>(plan, a, S, stream) : launch_dense<5, 0>(plan, a, S, stream); return true;
+        case 4: *rc = launch_dense<4, 0>(plan, a, S, stream); return true;
+        default: return false;
+    }
+}
+
 // ---- runtime-specialised kernels (cpf_jit.h).  Which kernels a (plan, S, lw) launch would try, in order of
 // preference: used by the launch path and by cpf_jit_precompile (which builds them without a GPU).
 struct JitCandidate { cpf_jit::Spec spec; size_t lds = 0; std::string tag; };
@@ -362,6 +405,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t s
     // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
     // kernel; 3. generic per-gate kernel
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
+    if (try_dense(plan, a, S, stream, &rc)) return rc;
     const int lw = choose_lw(plan, S);
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) return rc;
@@ -386,6 +430,7 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
     { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
+    pl->h_place.assign(pb->placements, pb->placements + 2 * (size_t)pl->K);
     pl->layer_ud.clear();
     for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
         bool periodic = true;

@@ -1,0 +1,20 @@
+// Test shim: the 4x4 block algebra of the dense kernel (cpflow_amd/csrc/cpf_dense_math.h) compiled for the CPU.
+#include "cpf_dense_math.h"
+using namespace cpf::dense;
+struct ArrRec {
+    const float* p;
+    void operator()(int i, float& c, float& s, int& kind) const { c = p[4 * i]; s = p[4 * i + 1]; kind = (int)p[4 * i + 2]; }
+};
+extern "C" void dm_block_matrix(const float* rec, int n_rot, float* G) {
+    cx g[4][4];
+    block_matrix(g, ArrRec{rec}, n_rot);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = g[i][j].re; G[2 * (4 * i + j) + 1] = g[i][j].im; }
+}
+extern "C" void dm_block_gradient(const float* rec, int n_rot, const float* G, const float* M, float* grad) {
+    cx g[4][4], m[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        g[i][j] = mk(G[2 * (4 * i + j)], G[2 * (4 * i + j) + 1]);
+        m[i][j] = mk(M[2 * (4 * i + j)], M[2 * (4 * i + j) + 1]);
+    }
+    block_gradient(grad, g, m, ArrRec{rec}, n_rot);
+}

@@ -145,6 +145,7 @@ def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw
     frozen[1::2, ::5] = 1
     monkeypatch.setenv('CPF_LW', lw)
     monkeypatch.setenv('CPF_SPLIT', '0')          # the two-ended 3-qubit kernel has its own test below
+    monkeypatch.setenv('CPF_DENSE', '0')          # ... and so has the dense-block kernel
     outs = {}
     for jit in ('1', '0'):
         monkeypatch.setenv('CPF_JIT', jit)
@@ -406,3 +407,59 @@ def test_shipped_jit_cache_needs_no_compiler(monkeypatch):
     eng = _engine([[3, 1], [0, 2], [2, 3], [1, 0]], 9, target, 'yx', num_gd_iterations=2)
     with pytest.raises(ValueError, match='CPF_JIT_FORBID_COMPILE'):
         eng.optimize(eng.initial_angles(1, 8))
+
+
+DENSE_CASES = [
+    # (layer, K, rot, entangler, CPF_DENSE_LW or None)
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', None),                       # 4 qubits: both register bits, both lane bits
+    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', None),                 # twisted placements
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '0'),                # 5 qubits, 1 wave (16 amplitudes per thread)
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '1'),                # 5 qubits, 2 waves (8 per thread, two lane qubits)
+    ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cp', '1'),
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '1'),            # 6 qubits, 2 waves (32 per thread)
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '2'),            # 6 qubits, 4 waves (16 per thread)
+    ([[0, 5], [2, 3], [4, 1], [5, 4], [3, 5]], 7, 'zx', 'cp', '1'),
+    ([[5, 4], [4, 5], [0, 5], [4, 1]], 6, 'zyxz', 'cp', '2'),                # both qubits of a block on lanes; 4 rotation letters
+    ([[3, 0], [1, 2], [2, 3], [0, 1]], 7, 'xz', 'cz', None),                 # fixed entanglers (Ansatz 'cz' / 'cx')
+    ([[0, 5], [4, 2], [1, 3], [5, 1], [2, 0]], 6, 'zy', 'cx', '1'),
+    ([[1, 4], [4, 3], [2, 0]], 5, 'xyz', 'cx', '0'),
+]
+
+
+@pytest.mark.parametrize('layer,K,rot,ent,lw', DENSE_CASES)
+def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, monkeypatch):
+    """The dense-block kernel (cpf_dense.h: one 4x4 matrix per entangling block on a register-resident qubit pair, lane
+    qubits exchanged in and out with v_permlane swaps, angle gradients from the 4x4 environment) against the float64
+    oracle over a short Adam run with history, with the penalty on and with a frozen mask; every layout variant."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 5)
+    T, S = 12, 5
+    monkeypatch.setenv('CPF_DENSE', '1')
+    if lw is not None:
+        monkeypatch.setenv('CPF_DENSE_LW', lw)
+    kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(3, S)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    waves = {None: 1, '0': 1, '1': 2, '2': 4}[lw]
+    assert eng.last_variant() == f'dense/aot waves={waves}', eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6       # loss at the initial angles
+    assert np.abs(out['history_params'] - ref['history_params'])[:, :2].max() < 3e-5           # = the first gradient (Adam's first step is lr * sign-like)
+    assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 2e-5
+    assert np.abs(out['history_params'] - ref['history_params']).max() < 2e-4
+    assert (out['cz'] == ref['cz']).all() and (out['params'][:, 0] == init).all()
+    assert np.abs(out['reg'] - ref['reg']).max() < 1e-6
+    hp, best = out['history_params'], out['params'][:, 1]
+    for s in range(S):                                    # the best row is a visited iterate, bit for bit
+        assert any((best[s] == hp[s, t]).all() for t in range(T))
+    frozen = np.zeros((S, orc.P), dtype=np.uint8)
+    frozen[1::2, ::5] = 1
+    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
+    assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
+    monkeypatch.setenv('CPF_DENSE', '0')                  # the gate-by-gate kernels on the same inputs
+    eng0 = _engine(layer, K, target, rot, **kw)
+    out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
+    assert not eng0.last_variant().startswith('dense')
+    assert np.abs(outf['regloss'] - out0['regloss']).max() < 2e-5
