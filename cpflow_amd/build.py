@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_jit.h')
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_dense_math.h', 'cpf_dense_aot.h', 'cpf_dense_aot.hip', 'cpf_jit.h')
                 if os.path.exists(os.path.join(HERE, 'csrc', h))] + [os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
 JIT_DIR = os.path.join(HERE, 'jit_cache')      # shipped code objects of runtime-specialised kernels (git-ignored, travels with gpurun)
 OUT = os.path.join(HERE, 'libcpflow_amd.so')
@@ -23,10 +23,27 @@ def up_to_date():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
 
 
+# the dense-block kernels are their own translation unit: 32 amplitudes per thread only stay in registers with raised
+# alloca-promotion limits (cpf_dense_aot.h), which the other kernels are not built with
+DENSE_SRC = os.path.join(HERE, 'csrc', 'cpf_dense_aot.hip')
+DENSE_FLAGS = ['-mllvm', '-amdgpu-promote-alloca-to-vector-max-regs=128', '-mllvm', '-amdgpu-promote-alloca-to-vector-vgpr-ratio=1']
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [HIPCC] + FLAGS + ['-o', OUT, SRC, '-lhiprtc']
+    cflags = [f for f in FLAGS if f != '-shared']
+    objs = [(SRC, os.path.join(HERE, 'csrc', 'cpflow_amd.o'), []), (DENSE_SRC, os.path.join(HERE, 'csrc', 'cpf_dense_aot.o'), DENSE_FLAGS)]
+    procs = []
+    for src, obj, extra in objs:          # the two units compile side by side
+        cmd = [HIPCC] + cflags + extra + ['-c', '-o', obj, src]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait():
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + [o for _, o, _ in objs] + ['-lhiprtc']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -31,7 +31,7 @@
 //   backward C = f V; blocks K-1 .. 0 (fused pass above, M reduced over the wave -> LDS env); surface gates
 //   chain    thread b: angle gradients of block b from M_b (summed over waves) and G_b          [LDS: gw]
 #pragma once
-#include "cpf_blocks.h"
+#include "cpf_layered.h"
 #include "cpf_dense_math.h"
 
 namespace cpf {
@@ -68,13 +68,19 @@ struct DLay {
     __device__ static int col_index(int lane, int wave) {      // column bits: wave bits first (most significant), then lane bits
         return (wave << NLC) | (lane & ((1 << NLC) - 1));
     }
+    // row_index(lane, e) = row_of_lane(lane) | row_of_reg(e): the two parts use different bits
+    __host__ __device__ static constexpr int row_of_reg(int e) {
+        int r = 0;
+        for (int q = 0; q < NRR; q++) r |= ((e >> reg_bit(q)) & 1) << (NQ - 1 - q);
+        return r;
+    }
 };
 
 // ---- host side: the per-block table ----------------------------------------------------------------------------
 // up, dn: the placement (up = first qubit).  Lane qubits of the pair are exchanged with the lowest register qubits
 // outside the pair.
 template <class L>
-inline DenseBlock dense_block_entry(int up, int dn, int first_gate) {
+__host__ __device__ constexpr DenseBlock dense_block_entry(int up, int dn, int first_gate) {
     DenseBlock d{-1, -1, 0, first_gate};
     int pos_up = L::on_lane(up) ? -1 : L::reg_bit(up), pos_dn = L::on_lane(dn) ? -1 : L::reg_bit(dn);
     int next_q = 0, nswap = 0;
@@ -83,9 +89,9 @@ inline DenseBlock dense_block_entry(int up, int dn, int first_gate) {
         if (!L::on_lane(q)) continue;
         while (next_q == up || next_q == dn || L::on_lane(next_q)) next_q++;       // a register qubit outside the pair
         const int rb = L::reg_bit(next_q++);
-        (nswap == 0 ? d.x : d.y) = (L::lane_bit(q) << 8) | rb;
+        if (nswap == 0) d.x = (L::lane_bit(q) << 8) | rb; else d.y = (L::lane_bit(q) << 8) | rb;
         nswap++;
-        (which == 0 ? pos_up : pos_dn) = rb;
+        if (which == 0) pos_up = rb; else pos_dn = rb;
     }
     const int ra = pos_up < pos_dn ? pos_up : pos_dn, rb = pos_up < pos_dn ? pos_dn : pos_up;
     d.z = ra | (rb << 4) | (pos_up == ra ? 256 : 0);
@@ -93,11 +99,16 @@ inline DenseBlock dense_block_entry(int up, int dn, int first_gate) {
 }
 
 // ---- packed complex helpers --------------------------------------------------------------------------------------
-// acc += a * b / conj(a) * b with a, b (re, im) pairs: two v_pk_fma_f32 (the swaps and signs are op_sel / neg bits)
-__device__ __forceinline__ f2 cmac(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.y), f2{-b.y, b.x}, pk_fma(splat(a.x), b, acc)); }
-__device__ __forceinline__ f2 cmac_conj(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.y), f2{b.y, -b.x}, pk_fma(splat(a.x), b, acc)); }
-__device__ __forceinline__ f2 cmul0(f2 a, f2 b) { return pk_fma(splat(a.y), f2{-b.y, b.x}, splat(a.x) * b); }
-__device__ __forceinline__ f2 cmul0_conj(f2 a, f2 b) { return pk_fma(splat(a.y), f2{b.y, -b.x}, splat(a.x) * b); }
+// acc += a * b / conj(a) * b with a, b (re, im) register pairs: exactly two v_pk_fma_f32.  The sign sits on the broadcast
+// FACTOR (-a.y, a.y), which the compiler folds into neg_lo / neg_hi next to the op_sel half-selects; written with the sign
+// on the swapped operand (-b.y, b.x) it builds that pair with a v_xor and a v_mov per amplitude and pass (+25 % VALU).
+__device__ __forceinline__ f2 cmac(f2 acc, f2 a, f2 b) { return pk_fma(f2{-a.y, a.y}, swp(b), pk_fma(splat(a.x), b, acc)); }
+__device__ __forceinline__ f2 cmac_conj(f2 acc, f2 a, f2 b) { return pk_fma(f2{a.y, -a.y}, swp(b), pk_fma(splat(a.x), b, acc)); }
+// the two halves of a multiply-add separately, so that callers can advance several accumulators in lock step
+__device__ __forceinline__ f2 cmac_re(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.x), b, acc); }
+__device__ __forceinline__ f2 cmac_im(f2 acc, f2 a, f2 b, bool conj) { return conj ? pk_fma(f2{a.y, -a.y}, swp(b), acc) : pk_fma(f2{-a.y, a.y}, swp(b), acc); }
+__device__ __forceinline__ f2 cmul0(f2 a, f2 b) { return pk_fma(f2{-a.y, a.y}, swp(b), splat(a.x) * b); }
+__device__ __forceinline__ f2 cmul0_conj(f2 a, f2 b) { return pk_fma(f2{a.y, -a.y}, swp(b), splat(a.x) * b); }
 
 // exchange lane bit LB (4 or 5) with register bit RB of a matrix: one v_permlane{16,32}_swap per 32-bit register pair
 template <int E, int LB, int RB>
@@ -142,45 +153,93 @@ __device__ __forceinline__ void dense_apply(f2 (&x)[E], const f2 (&g)[16]) {
         if (e & ((1 << RA) | (1 << RB))) continue;
         const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
         const f2 in[4] = {x[idx[0]], x[idx[1]], x[idx[2]], x[idx[3]]};
+        // the four outputs advance together (j outer, i inner): four independent accumulation chains in program order, so
+        // that a lone wave does not wait out the 9-cycle dependent v_pk_fma_f32 latency (and its op_sel forwarding s_nop)
+        f2 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f2 acc = ADJ ? cmul0_conj(g[i], in[0]) : cmul0(g[4 * i], in[0]);
+        for (int i = 0; i < 4; i++) acc[i] = splat((ADJ ? g[i] : g[4 * i]).x) * in[0];
 #pragma unroll
-            for (int j = 1; j < 4; j++) acc = ADJ ? cmac_conj(acc, g[4 * j + i], in[j]) : cmac(acc, g[4 * i + j], in[j]);
-            x[idx[i]] = acc;
+        for (int i = 0; i < 4; i++) acc[i] = cmac_im(acc[i], ADJ ? g[i] : g[4 * i], in[0], ADJ);
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = cmac_re(acc[i], ADJ ? g[4 * j + i] : g[4 * i + j], in[j]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = cmac_im(acc[i], ADJ ? g[4 * j + i] : g[4 * i + j], in[j], ADJ);
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[idx[i]] = acc[i];
+        // one group at a time: left alone the scheduler interleaves all E / 4 groups and the live set leaves the register file
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-// backward pass of one block, fused per group of four amplitudes:  psi <- G^+ psi,  M_ij += conj(C_i) psi_j,  C <- G^+ C
-template <int E, int RA, int RB>
-__device__ __forceinline__ void dense_backward(f2 (&p)[E], f2 (&c)[E], const f2 (&g)[16], f2 (&m)[16]) {
+// backward pass of one block, fused per group of four amplitudes:  psi <- G^+ psi,  M_ij += conj(C_i) psi_j,  C <- G^+ C.
+// PART = 0: everything in one pass (16 complex accumulators).  PART = 1 / 2: the same in two passes over the groups with 8
+// accumulators each - rows 0, 1 of M while psi is un-applied, rows 2, 3 while C is - for layouts where psi, C and 16
+// accumulators do not fit the register file together (32 amplitudes per thread).
+template <int E, int RA, int RB, int PART>
+__device__ __forceinline__ void dense_backward(f2 (&p)[E], f2 (&c)[E], const f2 (&g)[16], f2 (&m)[PART == 0 ? 16 : 8]) {
+    constexpr int I0 = PART == 2 ? 2 : 0, NI = PART == 0 ? 4 : 2;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         if (e & ((1 << RA) | (1 << RB))) continue;
         const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
-        const f2 pin[4] = {p[idx[0]], p[idx[1]], p[idx[2]], p[idx[3]]};
         const f2 cin[4] = {c[idx[0]], c[idx[1]], c[idx[2]], c[idx[3]]};
         f2 pq[4];
+        if constexpr (PART != 2) {
+            const f2 pin[4] = {p[idx[0]], p[idx[1]], p[idx[2]], p[idx[3]]};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f2 acc = cmul0_conj(g[i], pin[0]);
+            for (int i = 0; i < 4; i++) pq[i] = splat(g[i].x) * pin[0];
 #pragma unroll
-            for (int j = 1; j < 4; j++) acc = cmac_conj(acc, g[4 * j + i], pin[j]);
-            pq[i] = acc;
-            p[idx[i]] = acc;
+            for (int i = 0; i < 4; i++) pq[i] = cmac_im(pq[i], g[i], pin[0], true);
+#pragma unroll
+            for (int j = 1; j < 4; j++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) pq[i] = cmac_re(pq[i], g[4 * j + i], pin[j]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) pq[i] = cmac_im(pq[i], g[4 * j + i], pin[j], true);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[idx[i]] = pq[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pq[i] = p[idx[i]];
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_conj(m[4 * i + j], cin[i], pq[j]);
+            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_re(m[4 * i + j], cin[I0 + i], pq[j]);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f2 acc = cmul0_conj(g[i], cin[0]);
-#pragma unroll
-            for (int j = 1; j < 4; j++) acc = cmac_conj(acc, g[4 * j + i], cin[j]);
-            c[idx[i]] = acc;
+            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_im(m[4 * i + j], cin[I0 + i], pq[j], true);
         }
+        if constexpr (PART != 1) {
+            f2 cq[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cq[i] = splat(g[i].x) * cin[0];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cq[i] = cmac_im(cq[i], g[i], cin[0], true);
+#pragma unroll
+            for (int j = 1; j < 4; j++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) cq[i] = cmac_re(cq[i], g[4 * j + i], cin[j]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) cq[i] = cmac_im(cq[i], g[4 * j + i], cin[j], true);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) c[idx[i]] = cq[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// The block matrix: eight broadcast ds_read_b128 into 16 (re, im) register pairs.  As VECTOR register pairs the factors
+// G_ij take part in v_pk_fma_f32 with their half-selects and signs as op_sel / neg bits (8 operations per amplitude and
+// pass, nothing else); held in scalar registers instead the compiler builds every (-im, im) and (-y, x) pair with two
+// extra VALU operations (measured: +37 % instructions in the forward sweep).
+__device__ __forceinline__ void load_block_matrix(const float* gm, f2 (&g)[16]) {
+    const float4* gp = reinterpret_cast<const float4*>(gm);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
 }
 
 #define CPF_PAIR_SWITCH(PAIR, BODY)                                                                   \
@@ -289,6 +348,38 @@ __device__ __forceinline__ void dense_env_reduce(const f2 (&m)[16], float* dst, 
     dst[dst_lane] = r;
 }
 
+// 16 values (8 complex accumulators, one half of the environment): value v summed over the wave, left in dst[v]
+__device__ __forceinline__ int dense_env_dst16(int lane) {
+    return 4 * (2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+}
+__device__ __forceinline__ void dense_env_reduce16(const f2 (&m)[8], float* dst, int dst_lane) {
+    float w[8], u[4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {                        // bit 5: values 2r (low half), 2r + 1 (high half); m[r] = (v[2r], v[2r + 1])
+        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[r].x), __float_as_uint(m[r].y), false, false);
+        w[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                        // bit 4
+        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r]), __float_as_uint(w[2 * r + 1]), false, false);
+        u[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+    float e0, e1, f0;                                    // bits 2, 3: reduce-scatter 4 -> 1 under bank masks (cpf_blocks.h)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(e0), "=&v"(e1), "=&v"(f0)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+    float r = f0 + dppz<0xB1>(f0);                       // bits 0, 1: plain sums (four lanes end with the same value)
+    r += dppz<0x4E>(r);
+    dst[dst_lane] = r;
+}
+
 // ---- LDS map (float offsets) -------------------------------------------------------------------------------------------
 struct DenseLds {
     int rec, gm, th, mm, vv, psl, gw, env, gsurf, red, total;
@@ -309,9 +400,14 @@ struct DenseLds {
 // ---- the kernel ---------------------------------------------------------------------------------------------------
 struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot; };
 
-template <int NQ, int LW>
-__global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
+// UD... = the layer as (up, dn) pairs (block b sits on pair b mod length): the block loops are then straight-line code per
+// layer with compile-time register bits and exchanges.  Empty UD: any circuit, every block dispatched through the table.
+template <int NQ, int LW, int... UD>
+__device__ __forceinline__ void dense_body(const DenseArgs& da) {
     using L = DLay<NQ, LW>;
+    using PL = PairList<UD...>;
+    constexpr int LL = sizeof...(UD) / 2;
+    constexpr bool HALVES = L::E >= 32;                  // environment accumulated in two halves (register budget)
     constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
     const KArgs& a = da.k;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -330,7 +426,16 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     const int col = L::col_index(lane, wave);
-    const int env_dst = dense_env_dst(lane), surf_dst = reduce8_dst_lane(lane);
+    const int env_dst = HALVES ? dense_env_dst16(lane) : dense_env_dst(lane), surf_dst = reduce8_dst_lane(lane);
+    // target element of (lane, e): one 32-bit byte offset per lane + a compile-time offset per e against the scalar base
+    // pointer (64-bit per-element addresses would be hoisted out of the step loop: 2 E registers for the whole run)
+    const char* tbase = reinterpret_cast<const char*>(a.target);
+    const uint32_t toff = (uint32_t)(L::row_index(lane, 0) * L::D + col) * 8u;
+    uint32_t toff_i = toff;
+    int lane_i = lane, col_i = col;
+    auto target_at = [&](int e) __attribute__((always_inline)) {
+        return *reinterpret_cast<const float2*>(tbase + (toff_i + (uint32_t)(L::row_of_reg(e) * L::D * 8)));
+    };
     float* env_w = smem + lds.env + wave * K * 32;
     float* gsurf_w = smem + lds.gsurf + wave * NBATCH * 32;
     const_i_ptr blk = (const_i_ptr)(const int*)da.blocks;          // scalar loads: the table is wave-uniform
@@ -369,6 +474,9 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
         const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
+        // per-lane constants pass through an opaque copy once per step: otherwise everything derived from them (the E
+        // identity amplitudes, the E target offsets) is hoisted out of the step loop and occupies registers for the whole run
+        asm volatile("" : "+v"(toff_i), "+v"(lane_i), "+v"(col_i));
         // ================= build: G_b from the gate records, one thread per block
         for (int b = tid; b < K; b += THREADS) {
             const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
@@ -389,26 +497,46 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
 
         // ================= forward
 #pragma unroll
-        for (int e = 0; e < E; e++) psi[e] = f2{(L::row_index(lane, e) == col) ? 1.f : 0.f, 0.f};
-        for (int q = 0; q < NQ; q++) {                     // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
-            const float4 r0 = rec[3 * q], r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
+        for (int e = 0; e < E; e++) psi[e] = f2{(L::row_index(lane_i, e) == col_i) ? 1.f : 0.f, 0.f};
+        static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
+            constexpr int Q = decltype(qq)::value;
+            const float4 r0 = rec[3 * Q], r1 = rec[3 * Q + 1], r2 = rec[3 * Q + 2];
             // a lane qubit borrows register bit 0 (qubit NRR-1) for its three gates
-            const int sw = L::on_lane(q) ? ((L::lane_bit(q) << 8) | 0) : -1, bit = L::on_lane(q) ? 0 : L::reg_bit(q);
-            do_swap<L>(psi, sw);
-            CPF_BIT_SWITCH(bit, (rot_reg<E, OP_RZ, BIT>(psi, r0.x, r0.y), rot_reg<E, OP_RX, BIT>(psi, r1.x, r1.y), rot_reg<E, OP_RZ, BIT>(psi, r2.x, r2.y)));
-            do_swap<L>(psi, sw);
-        }
-        for (int b = 0; b < K; b++) {
-            const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
-            f2 g[16];
-            const float4* gp = reinterpret_cast<const float4*>(smem + lds.gm + 32 * b);
-#pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
-            do_swap<L>(psi, sx);
-            do_swap<L>(psi, sy);
-            CPF_PAIR_SWITCH(pair, (dense_apply<E, RA, RB, false>(psi, g)));
-            do_swap<L>(psi, sy);
-            do_swap<L>(psi, sx);
+            constexpr int BIT = L::on_lane(Q) ? 0 : L::reg_bit(Q);
+            if constexpr (L::on_lane(Q)) swap_lane_reg<E, L::lane_bit(Q), 0>(psi);
+            rot_reg<E, OP_RZ, BIT>(psi, r0.x, r0.y);
+            rot_reg<E, OP_RX, BIT>(psi, r1.x, r1.y);
+            rot_reg<E, OP_RZ, BIT>(psi, r2.x, r2.y);
+            if constexpr (L::on_lane(Q)) swap_lane_reg<E, L::lane_bit(Q), 0>(psi);
+        }, typename make_iseq<NQ>::type{});
+        if constexpr (LL == 0) {
+            for (int b = 0; b < K; b++) {
+                const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
+                f2 g[16];
+                load_block_matrix(smem + lds.gm + 32 * b, g);
+                do_swap<L>(psi, sx);
+                do_swap<L>(psi, sy);
+                CPF_PAIR_SWITCH(pair, (dense_apply<E, RA, RB, false>(psi, g)));
+                do_swap<L>(psi, sy);
+                do_swap<L>(psi, sx);
+            }
+        } else {
+            int b = 0;
+            auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
+                constexpr int J = decltype(jj)::value;
+                constexpr DenseBlock ent = dense_block_entry<L>(PL::v[2 * J], PL::v[2 * J + 1], 0);
+                constexpr int RA = ent.z & 15, RB = (ent.z >> 4) & 15;
+                f2 g[16];
+                load_block_matrix(smem + lds.gm + 32 * b, g);
+                if constexpr (ent.x >= 0) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                dense_apply<E, RA, RB, false>(psi, g);
+                if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                if constexpr (ent.x >= 0) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                b++;
+            };
+            for (int full = K / LL; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
+            static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); }, typename make_iseq<LL>::type{});
         }
 
         // ================= loss (matrix_utils.py:35-42) and penalty (main.py:563-564)
@@ -417,7 +545,7 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
             f2 tt = {0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const float2 t = a.target[L::row_index(lane, e) * L::D + col];
+                const float2 t = target_at(e);
                 if (a.loss_kind == 2) acc[0] = fmaf(fmaf(t.x, t.x, t.y * t.y), fmaf(psi[e].x, psi[e].x, psi[e].y * psi[e].y), acc[0]);
                 else { tt = pk_fma(splat(t.x), psi[e], tt); tt = pk_fma(f2{t.y, -t.y}, swp(psi[e]), tt); }
             }
@@ -466,43 +594,79 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
             const float fr = -a.inv_dim2 * tr, fi = -a.inv_dim2 * ti;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const float2 t = a.target[L::row_index(lane, e) * L::D + col];
+                const float2 t = target_at(e);
                 if (a.loss_kind == 2) cot[e] = splat(-a.inv_dim2 * fmaf(t.x, t.x, t.y * t.y)) * psi[e];
                 else cot[e] = cmul(f2{t.x, t.y}, f2{fr, fi});
             }
         }
-        for (int b = K - 1; b >= 0; b--) {
-            const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
-            f2 g[16], m[16];
-            const float4* gp = reinterpret_cast<const float4*>(smem + lds.gm + 32 * b);
+        // one block of the backward sweep on register bits RA < RB (psi and C already hold the pair in registers)
+        auto bwd_block = [&](auto ra, auto rb, const f2 (&g)[16], int b) __attribute__((always_inline)) {
+            constexpr int RA = decltype(ra)::value, RB = decltype(rb)::value;
+            if constexpr (HALVES) {
+                f2 m[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
+                for (int i = 0; i < 8; i++) m[i] = f2{0.f, 0.f};
+                dense_backward<E, RA, RB, 1>(psi, cot, g, m);
+                dense_env_reduce16(m, env_w + 32 * b, env_dst);
 #pragma unroll
-            for (int i = 0; i < 16; i++) m[i] = f2{0.f, 0.f};
-            do_swap<L>(psi, sx); do_swap<L>(cot, sx);
-            do_swap<L>(psi, sy); do_swap<L>(cot, sy);
-            CPF_PAIR_SWITCH(pair, (dense_backward<E, RA, RB>(psi, cot, g, m)));
-            do_swap<L>(psi, sy); do_swap<L>(cot, sy);
-            do_swap<L>(psi, sx); do_swap<L>(cot, sx);
-            dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+                for (int i = 0; i < 8; i++) m[i] = f2{0.f, 0.f};
+                dense_backward<E, RA, RB, 2>(psi, cot, g, m);
+                dense_env_reduce16(m, env_w + 32 * b + 16, env_dst);
+            } else {
+                f2 m[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) m[i] = f2{0.f, 0.f};
+                dense_backward<E, RA, RB, 0>(psi, cot, g, m);
+                dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+            }
+        };
+        if constexpr (LL == 0) {
+            for (int b = K - 1; b >= 0; b--) {
+                const int sx = blk[4 * b], sy = blk[4 * b + 1], pair = blk[4 * b + 2] & 255;
+                f2 g[16];
+                load_block_matrix(smem + lds.gm + 32 * b, g);
+                do_swap<L>(psi, sx); do_swap<L>(cot, sx);
+                do_swap<L>(psi, sy); do_swap<L>(cot, sy);
+                CPF_PAIR_SWITCH(pair, (bwd_block(ic<RA>{}, ic<RB>{}, g, b)));
+                do_swap<L>(psi, sy); do_swap<L>(cot, sy);
+                do_swap<L>(psi, sx); do_swap<L>(cot, sx);
+            }
+        } else {
+            int b = K - 1;
+            auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
+                constexpr int J = LL - 1 - decltype(jj)::value;
+                constexpr DenseBlock ent = dense_block_entry<L>(PL::v[2 * J], PL::v[2 * J + 1], 0);
+                f2 g[16];
+                load_block_matrix(smem + lds.gm + 32 * b, g);
+                if constexpr (ent.x >= 0) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
+                bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, g, b);
+                if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
+                if constexpr (ent.x >= 0) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                b--;
+            };
+            const int tail = K % LL;                         // blocks beyond the last whole layer come first
+            static_for([&](auto jj) __attribute__((always_inline)) { if (LL - 1 - decltype(jj)::value < tail) bwd_step(jj); },
+                       typename make_iseq<LL>::type{});
+            for (int full = K / LL; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
         }
         {   // surface gates, backwards: gradient right after each gate, then un-apply it from psi and C
             float ds[8 * NBATCH];
 #pragma unroll
             for (int k = 0; k < 8 * NBATCH; k++) ds[k] = 0.f;
-            for (int q = NQ - 1; q >= 0; q--) {
-                const float4 r0 = rec[3 * q], r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
-                const int sw = L::on_lane(q) ? ((L::lane_bit(q) << 8) | 0) : -1, bit = L::on_lane(q) ? 0 : L::reg_bit(q);
-                do_swap<L>(psi, sw); do_swap<L>(cot, sw);
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-                CPF_BIT_SWITCH(bit, (d2 = rot_reg_grad<E, OP_RZ, BIT>(psi, cot), rot_reg<E, OP_RZ, BIT>(psi, r2.x, -r2.y), rot_reg<E, OP_RZ, BIT>(cot, r2.x, -r2.y),
-                                     d1 = rot_reg_grad<E, OP_RX, BIT>(psi, cot), rot_reg<E, OP_RX, BIT>(psi, r1.x, -r1.y), rot_reg<E, OP_RX, BIT>(cot, r1.x, -r1.y),
-                                     d0 = rot_reg_grad<E, OP_RZ, BIT>(psi, cot), rot_reg<E, OP_RZ, BIT>(psi, r0.x, -r0.y), rot_reg<E, OP_RZ, BIT>(cot, r0.x, -r0.y)));
-                do_swap<L>(psi, sw); do_swap<L>(cot, sw);
-                // static slots: q is a loop variable, ds a register array
-#pragma unroll
-                for (int qq = 0; qq < NQ; qq++) if (qq == q) { ds[3 * qq] = d0; ds[3 * qq + 1] = d1; ds[3 * qq + 2] = d2; }
-            }
+            static_for([&](auto qq) __attribute__((always_inline)) {
+                constexpr int Q = NQ - 1 - decltype(qq)::value;
+                const float4 r0 = rec[3 * Q], r1 = rec[3 * Q + 1], r2 = rec[3 * Q + 2];
+                constexpr int BIT = L::on_lane(Q) ? 0 : L::reg_bit(Q);
+                if constexpr (L::on_lane(Q)) { swap_lane_reg<E, L::lane_bit(Q), 0>(psi); swap_lane_reg<E, L::lane_bit(Q), 0>(cot); }
+                ds[3 * Q + 2] = rot_reg_grad<E, OP_RZ, BIT>(psi, cot);
+                rot_reg<E, OP_RZ, BIT>(psi, r2.x, -r2.y); rot_reg<E, OP_RZ, BIT>(cot, r2.x, -r2.y);
+                ds[3 * Q + 1] = rot_reg_grad<E, OP_RX, BIT>(psi, cot);
+                rot_reg<E, OP_RX, BIT>(psi, r1.x, -r1.y); rot_reg<E, OP_RX, BIT>(cot, r1.x, -r1.y);
+                ds[3 * Q] = rot_reg_grad<E, OP_RZ, BIT>(psi, cot);
+                rot_reg<E, OP_RZ, BIT>(psi, r0.x, -r0.y); rot_reg<E, OP_RZ, BIT>(cot, r0.x, -r0.y);
+                if constexpr (L::on_lane(Q)) { swap_lane_reg<E, L::lane_bit(Q), 0>(psi); swap_lane_reg<E, L::lane_bit(Q), 0>(cot); }
+            }, typename make_iseq<NQ>::type{});
 #pragma unroll
             for (int bt = 0; bt < NBATCH; bt++) {
                 float d8[8];
@@ -590,6 +754,11 @@ __global__ __launch_bounds__(64 << LW, 2) void k_cp_dense(const DenseArgs da) {
         a.out_cz[s_idx] = (int32_t)acc[2];
         a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
     }
+}
+
+template <int NQ, int LW, int... UD>
+__global__ __launch_bounds__(64 << LW, (DLay<NQ, LW>::E >= 32 ? 1 : 2)) void k_cp_dense(const DenseArgs da) {
+    dense_body<NQ, LW, UD...>(da);
 }
 
 }  // namespace cpf

@@ -814,6 +814,7 @@ __global__ __launch_bounds__(64 << LW) void k_cp_template(const KArgs a) {
 // ------------------------------------------------------------------ reg(theta) for arbitrary angle rows
 // r * sum_i R(theta_i * mask_i) (main.py:563-564), one thread per row: the recomputation
 // jit(vmap(vmap(regularization_func))) of optimization.py:365-367 for history rows.
+#ifndef CPF_NO_PLAIN_KERNELS          // non-template kernels: defined by one translation unit only (cpflow_amd.hip)
 __global__ void k_reg_rows(const KArgs a, const float* theta, int64_t count, float* reg) {
     __shared__ __attribute__((aligned(16))) float tab[PEN_FLOATS + 4];
     penalty_table_init(tab, a, threadIdx.x);
@@ -826,6 +827,8 @@ __global__ void k_reg_rows(const KArgs a, const float* theta, int64_t count, flo
             if (a.pkind[j]) { float sl; acc += penalty_lds(tab, a.pen_kind, theta[row * a.P + j], sl); }
     reg[row] = a.use_reg ? a.r * acc : 0.f;
 }
+
+#endif
 
 // ------------------------------------------------------------------ initial angles (jax threefry2x32)
 // Restates what jax.random does for  main.py:541-548 / cp_utils.py:31-35 / trigonometric_utils.py:35-38:
@@ -868,6 +871,7 @@ __device__ __forceinline__ float erfinv_xla_f32(float x) {
     return p * x;
 }
 // cp_mode: 0 'uniform', 1 '0' (CP angles zero), 2 'normal' (CP angles 1.5 * normal(split(key')[1]), cp_utils.py:38-40)
+#ifndef CPF_NO_PLAIN_KERNELS
 __global__ void k_initial_angles(uint32_t seed, uint32_t s_total, uint32_t first, uint32_t count, uint32_t P,
                                  const uint8_t* pkind, int cp_mode, float* out) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -893,5 +897,7 @@ __global__ void k_initial_angles(uint32_t seed, uint32_t s_total, uint32_t first
     }
     out[idx] = f;
 }
+
+#endif
 
 }  // namespace cpf

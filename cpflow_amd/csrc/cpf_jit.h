@@ -120,7 +120,13 @@ inline int run_hipcc(const std::vector<std::string>& argv, const std::string& lo
 
 // what to build: `header` is the file under csrc/ that defines `body` (e.g. "cpf_layered.h",
 // "cpf::layered_body<4, 0, 8451, 3, 0, 0, 1, 1, 2, 2, 3>"), `threads` the workgroup size
-struct Spec { std::string header, body; int threads = 64; };
+struct Spec {
+    std::string header, body;
+    int threads = 64;
+    std::string arg = "cpf::KArgs";          // kernel argument type
+    int min_waves = 1;                       // second __launch_bounds__ argument (waves per SIMD the register allocator must allow)
+    std::vector<std::string> flags;          // extra compiler flags (e.g. -mllvm options)
+};
 
 struct Code { std::string bytes, backend, error; bool compiled = false; };    // backend: "hipcc" | "hiprtc"
 
@@ -131,11 +137,11 @@ inline Code build(const Spec& sp) {
     Code out;
     const std::string inc = lib_dir() + "/csrc";
     std::string hdrs;
-    for (const char* h : {"cpf_device.h", "cpf_blocks.h", "cpf_layered.h", "cpf_split.h", "cpf_dense.h"}) hdrs += read_file(inc + "/" + h);
+    for (const char* h : {"cpf_device.h", "cpf_blocks.h", "cpf_layered.h", "cpf_split.h", "cpf_dense.h", "cpf_dense_math.h"}) hdrs += read_file(inc + "/" + h);
     if (hdrs.size() < 1000) { out.error = "kernel headers not found under " + inc; return out; }
     // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
     const std::string src = "#include \"" + sp.header + "\"\nextern \"C\" __global__ __launch_bounds__(" + std::to_string(sp.threads) +
-                            ", 1) void cpf_jit_kernel(const cpf::KArgs a) {\n    " + sp.body + "(a);\n}\n";
+                            ", " + std::to_string(sp.min_waves) + ") void cpf_jit_kernel(const " + sp.arg + " a) {\n    " + sp.body + "(a);\n}\n";
     // Backend: the offline compiler as a child process by default.  hiprtc builds the same source with the same flags,
     // but on the MI355X boxes its code came out 2x slower (SGPR spills through v_writelane / v_readlane, 4477 vs 3536
     // instructions for the 3-qubit chain kernel: 20.6 ms vs 11.0 ms on config 2); it is the fallback when no hipcc is
@@ -147,7 +153,9 @@ inline Code build(const Spec& sp) {
     const bool have_hipcc = stat(hipcc.c_str(), &st_) == 0;
     auto name_for = [&](const char* backend) {
         char hname[64];
-        snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(src + backend, fnv1a(hdrs)));
+        std::string salt = src + backend;
+        for (const std::string& f : sp.flags) salt += f;
+        snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(salt, fnv1a(hdrs)));
         return std::string(hname) + ".hsaco";
     };
     // an object built by hipcc is the preferred one wherever it is found, whatever could be built here and now
@@ -169,8 +177,11 @@ inline Code build(const Spec& sp) {
         const std::string cpath = cdir + "/" + name_for("hipcc"), tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
         const std::string spath = tmp + ".hip";
         { std::ofstream o(spath); o << src; }
-        const int rc = run_hipcc({hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "--genco",
-                                  "-I" + inc, "-o", tmp, spath}, tmp + ".log");
+        std::vector<std::string> argv = {hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", "--genco"};
+        for (const std::string& f : sp.flags) argv.push_back(f);
+        for (const char* t : {"-I", "-o"}) (void)t;
+        argv.push_back("-I" + inc); argv.push_back("-o"); argv.push_back(tmp); argv.push_back(spath);
+        const int rc = run_hipcc(argv, tmp + ".log");
         unlink(spath.c_str());
         if (rc == 0) {
             out.bytes = read_file(tmp);
@@ -184,8 +195,9 @@ inline Code build(const Spec& sp) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "cpf_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { out.error += "hiprtcCreateProgram failed"; return out; }
     const std::string i1 = "-I" + inc, i2 = "-I/opt/rocm/include";
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", i1.c_str(), i2.c_str()};
-    if (hiprtcCompileProgram(prog, 7, opts) != HIPRTC_SUCCESS) {
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-signed-zeros", i1.c_str(), i2.c_str()};
+    for (const std::string& f : sp.flags) opts.push_back(f.c_str());
+    if (hiprtcCompileProgram(prog, (int)opts.size(), opts.data()) != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
         std::string log(n, '\0');

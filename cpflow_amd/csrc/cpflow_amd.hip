@@ -19,6 +19,7 @@
 #include "cpf_layered.h"
 #include "cpf_split.h"
 #include "cpf_dense.h"
+#include "cpf_dense_aot.h"
 #include "cpf_jit.h"
 
 namespace {
@@ -257,43 +258,105 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
     return false;
 }
 
-// ---- dense-block kernel (cpf_dense.h): 4..6 qubits, any layer / rotation string / entangler, no runtime compilation
-template <int NQ, int LW>
-int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
-    using L = cpf::DLay<NQ, LW>;
-    DevBuf& tab = plan->dense_tab[LW];
+// ---- dense-block kernel (cpf_dense.h): 4..6 qubits, any layer / rotation string / entangler.  In order of preference:
+// a layer-specialised instance built ahead of time (cpf_dense_aot.hip), one built at run time (cpf_jit.h), the
+// table-dispatched instance (no compiler needed, ~1.5x slower: a scalar branch tree per block).
+template <class L>
+int dense_table(cpf_plan* plan, DevBuf& tab) {
+    if (tab.p) return 0;
     const int K = plan->K, per_block = 1 + 2 * plan->n_rot;
-    if (!tab.p) {
-        std::vector<cpf::DenseBlock> h((size_t)K);
-        for (int b = 0; b < K; b++) h[b] = cpf::dense_block_entry<L>(plan->h_place[2 * b], plan->h_place[2 * b + 1], 3 * plan->n + per_block * b);
-        CPF_HIP(tab.alloc(h.size() * sizeof(cpf::DenseBlock)));
-        CPF_HIP(hipMemcpy(tab.p, h.data(), h.size() * sizeof(cpf::DenseBlock), hipMemcpyHostToDevice));
-    }
-    const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, K, NQ, L::WPS).total * sizeof(float);
-    if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
-    if (lds > 64 * 1024)
-        CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_dense<NQ, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), K, plan->n_rot};
-    hipLaunchKernelGGL((cpf::k_cp_dense<NQ, LW>), dim3((unsigned)S), dim3(L::THREADS), lds, stream, da);
-    CPF_HIP(hipGetLastError());
-    plan->variant = std::string("dense/aot waves=") + std::to_string(L::WPS);
+    std::vector<cpf::DenseBlock> h((size_t)K);
+    for (int b = 0; b < K; b++) h[b] = cpf::dense_block_entry<L>(plan->h_place[2 * b], plan->h_place[2 * b + 1], 3 * plan->n + per_block * b);
+    CPF_HIP(tab.alloc(h.size() * sizeof(cpf::DenseBlock)));
+    CPF_HIP(hipMemcpy(tab.p, h.data(), h.size() * sizeof(cpf::DenseBlock), hipMemcpyHostToDevice));
     return 0;
 }
-// 6 qubits: 2 waves per sample (32 amplitudes per thread), 4 on request; 5 qubits: 1 wave (16 per thread) while the samples
-// fill the SIMDs, else 2 (8 per thread); 4 qubits (4 per thread): the 32-value environment reduction costs as much as the
-// block there, so the gate-by-gate kernel stays the default (CPF_DENSE=1 selects the dense one).
-bool try_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
+// layers with an ahead-of-time specialised instance (cpf_dense_aot.hip)
+bool dense_has_aot(int nq, int lw, const std::vector<int>& ud) {
+    static const std::vector<std::pair<int, std::vector<int>>> aot = {
+        {6 * 8 + 1, {0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}}, {6 * 8 + 2, {0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}},
+        {5 * 8 + 0, {0, 1, 1, 2, 2, 3, 3, 4}}, {4 * 8 + 0, {0, 1, 1, 2, 2, 3}}};
+    for (const auto& kv : aot) if (kv.first == nq * 8 + lw && kv.second == ud) return true;
+    return false;
+}
+cpf_jit::Spec dense_jit_spec(int nq, int lw, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_dense.h", cpf_jit::body_expr("dense_body", {nq, lw}, ud), 64 << lw};
+    spec.arg = "cpf::DenseArgs";
+    spec.min_waves = (nq == 6 && lw == 1) ? 1 : 2;
+    spec.flags = {CPF_DENSE_MLLVM_FLAGS};
+    return spec;
+}
+bool dense_wanted(const cpf_plan* plan, int mode) {
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
     const char* e = getenv("CPF_DENSE");
-    if (e ? e[0] == '0' : plan->NQ == 4) return false;
+    return e ? e[0] != '0' : plan->NQ == 6;
+}
+int dense_lw(const cpf_plan* plan, int64_t S) {
     const char* w = getenv("CPF_DENSE_LW");
     const int64_t simds = (int64_t)plan->num_cu * 4;
     switch (plan->NQ) {
-        case 6: *rc = (w && w[0] == '2') ? launch_dense<6, 2>(plan, a, S, stream) : launch_dense<6, 1>(plan, a, S, stream); return true;
-        case 5: *rc = (w ? w[0] == '1' : 2 * S < simds) ? launch_dense<5, 1>(plan, a, S, stream) : launch_dense<5, 0>(plan, a, S, stream); return true;
-        case 4: *rc = launch_dense<4, 0>(plan, a, S, stream); return true;
-        default: return false;
+        case 6: return (w && w[0] == '2') ? 2 : 1;
+        case 5: return (w ? w[0] == '1' : 2 * S < simds) ? 1 : 0;
+        default: return 0;
     }
+}
+bool dense_specialised(const cpf_plan* plan) {
+    const char* sp = getenv("CPF_DENSE_SPECIALISED");               // A/B and tests: 0 = table-dispatched instance only
+    return !(sp && sp[0] == '0') && !plan->layer_ud.empty() && plan->layer_ud.size() <= 32;
+}
+
+int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S, hipStream_t stream) {
+    DevBuf& tab = plan->dense_tab[lw];
+    int rc = 0;
+    switch (nq * 8 + lw) {
+        case 6 * 8 + 1: rc = dense_table<cpf::DLay<6, 1>>(plan, tab); break;
+        case 6 * 8 + 2: rc = dense_table<cpf::DLay<6, 2>>(plan, tab); break;
+        case 5 * 8 + 0: rc = dense_table<cpf::DLay<5, 0>>(plan, tab); break;
+        case 5 * 8 + 1: rc = dense_table<cpf::DLay<5, 1>>(plan, tab); break;
+        case 4 * 8 + 0: rc = dense_table<cpf::DLay<4, 0>>(plan, tab); break;
+        default: return fail(-2, "no dense layout for %d qubits, %d waves", nq, 1 << lw);
+    }
+    if (rc) return rc;
+    const int wps = 1 << lw, threads = 64 << lw;
+    const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, plan->K, nq, wps).total * sizeof(float);
+    if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
+    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot};
+    const bool specialised = dense_specialised(plan);
+    // 1. run-time specialised (shipped cache / compile) unless an ahead-of-time instance of this very layer exists
+    hipError_t e = hipSuccess;
+    const std::string waves = " waves=" + std::to_string(wps);
+    if (specialised) {
+        const bool have_aot = dense_has_aot(nq, lw, plan->layer_ud);
+        if (!have_aot && plan->use_jit) {
+            const cpf_jit::Spec spec = dense_jit_spec(nq, lw, plan->layer_ud);
+            const cpf_jit::Kernel& k = cpf_jit::get(plan->device, spec);
+            if (k.fn) {
+                if (lds > 64 * 1024) CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                cpf::DenseArgs args = da;
+                void* params[] = {&args};
+                e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
+                plan->variant = "dense/jit(" + k.backend + ")" + waves;
+                return e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+            }
+            plan->jit_note = k.error;
+            if (k.error.find("forbidden") != std::string::npos) return fail(-30, "%s", k.error.c_str());
+        }
+    }
+    const int kind = cpf_dense_launch_aot(nq, lw, plan->layer_ud, specialised, da, S, lds, stream, &e);
+    if (kind == 0) return fail(-2, "no dense kernel for %d qubits, %d waves", nq, wps);
+    if (e != hipSuccess) return fail((int)e, "dense kernel launch failed: %s", hipGetErrorString(e));
+    plan->variant = std::string(kind == 1 ? "dense/aot" : "dense/table") + waves + (kind == 2 && !plan->jit_note.empty() ? " (" + plan->jit_note + ")" : "");
+    return 0;
+}
+// Default for 6 qubits (2 waves per sample, 32 amplitudes per thread; 4 waves on request): config 5 runs 756 ms against
+// 896 ms on the gate-by-gate kernel.  With 16 or fewer amplitudes per thread the fixed costs of a block - the 32-value
+// environment reduction, the exchanges of lane qubits, the 128-byte matrix load - weigh as much as its arithmetic: 5 qubits
+// 150 vs 144 ms, 4 qubits (config 4) 122 vs 58 ms, so there the gate-by-gate kernels stay the default (CPF_DENSE=1 selects the
+// dense one: 5 qubits 1 wave per sample while the samples fill the SIMDs, else 2).
+bool try_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (!dense_wanted(plan, a.mode)) return false;
+    *rc = launch_dense(plan, a, plan->NQ, dense_lw(plan, S), S, stream);
+    return true;
 }
 
 // ---- runtime-specialised kernels (cpf_jit.h).  Which kernels a (plan, S, lw) launch would try, in order of
@@ -678,6 +741,18 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     std::string report;
     int built = 0;
     const int loss_kind = pb->loss_kind == CPF_LOSS_RELATIVE_PHASE ? 2 : 0;
+    if (dense_wanted(&pl, cpf::MODE_OPTIMIZE)) {          // the dense-block kernel serves this shape: its layer-specialised instance
+        const int lw = dense_lw(&pl, num_samples);
+        if (dense_specialised(&pl) && !dense_has_aot(pl.NQ, lw, pl.layer_ud)) {
+            const cpf_jit::Spec spec = dense_jit_spec(pl.NQ, lw, pl.layer_ud);
+            const cpf_jit::Code code = cpf_jit::build(spec);
+            if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
+            report = "dense/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+            built = 1;
+        }
+        if (buf && size) snprintf(buf, size, "%s", report.c_str());
+        return built;
+    }
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, choose_lw(&pl, num_samples), num_samples)) {
         const cpf_jit::Code code = cpf_jit::build(c.spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", c.spec.body.c_str(), code.error.c_str());

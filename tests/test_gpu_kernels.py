@@ -401,7 +401,7 @@ def test_shipped_jit_cache_needs_no_compiler(monkeypatch):
     for K, S in ((23, 500), (29, 2048), (14, 40)):
         eng = _engine(layer, K, target, 'xyz', num_gd_iterations=5)
         eng.optimize(eng.initial_angles(1, S))
-        assert eng.last_variant().split(' ')[0] in ('layered/jit(hipcc)', 'dense/jit(hipcc)'), eng.last_variant()
+        assert eng.last_variant().split(' ')[0] == 'layered/jit(hipcc)', eng.last_variant()
     assert _ffi.lib().cpf_jit_compiles() == before
     # a shape nobody shipped fails loudly instead of compiling
     eng = _engine([[3, 1], [0, 2], [2, 3], [1, 0]], 9, target, 'yx', num_gd_iterations=2)
@@ -410,24 +410,26 @@ def test_shipped_jit_cache_needs_no_compiler(monkeypatch):
 
 
 DENSE_CASES = [
-    # (layer, K, rot, entangler, CPF_DENSE_LW or None)
-    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', None),                       # 4 qubits: both register bits, both lane bits
-    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', None),                 # twisted placements
-    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '0'),                # 5 qubits, 1 wave (16 amplitudes per thread)
-    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '1'),                # 5 qubits, 2 waves (8 per thread, two lane qubits)
-    ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cp', '1'),
-    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '1'),            # 6 qubits, 2 waves (32 per thread)
-    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '2'),            # 6 qubits, 4 waves (16 per thread)
-    ([[0, 5], [2, 3], [4, 1], [5, 4], [3, 5]], 7, 'zx', 'cp', '1'),
-    ([[5, 4], [4, 5], [0, 5], [4, 1]], 6, 'zyxz', 'cp', '2'),                # both qubits of a block on lanes; 4 rotation letters
-    ([[3, 0], [1, 2], [2, 3], [0, 1]], 7, 'xz', 'cz', None),                 # fixed entanglers (Ansatz 'cz' / 'cx')
-    ([[0, 5], [4, 2], [1, 3], [5, 1], [2, 0]], 6, 'zy', 'cx', '1'),
-    ([[1, 4], [4, 3], [2, 0]], 5, 'xyz', 'cx', '0'),
+    # (layer, K, rot, entangler, CPF_DENSE_LW or None, how the block loop is built: ahead-of-time specialised layer / table dispatch / run-time build)
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', None, 'aot'),                # 4 qubits: both register bits, both lane bits
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', None, 'table'),
+    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', None, 'table'),        # twisted placements
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '0', 'aot'),         # 5 qubits, 1 wave (16 amplitudes per thread)
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '1', 'table'),       # 5 qubits, 2 waves (8 per thread, two lane qubits)
+    ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cp', '1', 'jit'),
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '1', 'aot'),     # 6 qubits, 2 waves (32 per thread)
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '1', 'table'),
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '2', 'aot'),     # 6 qubits, 4 waves (16 per thread)
+    ([[0, 5], [2, 3], [4, 1], [5, 4], [3, 5]], 7, 'zx', 'cp', '1', 'table'),
+    ([[5, 4], [4, 5], [0, 5], [4, 1]], 6, 'zyxz', 'cp', '2', 'table'),       # both qubits of a block on lanes; 4 rotation letters
+    ([[3, 0], [1, 2], [2, 3], [0, 1]], 7, 'xz', 'cz', None, 'table'),        # fixed entanglers (Ansatz 'cz' / 'cx')
+    ([[0, 5], [4, 2], [1, 3], [5, 1], [2, 0]], 6, 'zy', 'cx', '1', 'table'),
+    ([[1, 4], [4, 3], [2, 0]], 5, 'xyz', 'cx', '0', 'table'),
 ]
 
 
-@pytest.mark.parametrize('layer,K,rot,ent,lw', DENSE_CASES)
-def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, monkeypatch):
+@pytest.mark.parametrize('layer,K,rot,ent,lw,how', DENSE_CASES)
+def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypatch):
     """The dense-block kernel (cpf_dense.h: one 4x4 matrix per entangling block on a register-resident qubit pair, lane
     qubits exchanged in and out with v_permlane swaps, angle gradients from the 4x4 environment) against the float64
     oracle over a short Adam run with history, with the penalty on and with a frozen mask; every layout variant."""
@@ -435,6 +437,7 @@ def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, monkeypatch):
     target = _rand_unitary(n, 5)
     T, S = 12, 5
     monkeypatch.setenv('CPF_DENSE', '1')
+    monkeypatch.setenv('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
     if lw is not None:
         monkeypatch.setenv('CPF_DENSE_LW', lw)
     kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
@@ -443,7 +446,7 @@ def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, monkeypatch):
     init = orc.initial_angles(3, S)
     out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
     waves = {None: 1, '0': 1, '1': 2, '2': 4}[lw]
-    assert eng.last_variant() == f'dense/aot waves={waves}', eng.last_variant()
+    assert eng.last_variant() == {'aot': 'dense/aot', 'table': 'dense/table', 'jit': 'dense/jit(hipcc)'}[how] + f' waves={waves}', eng.last_variant()
     ref = orc.run(init, np.float64, keep_history=True)
     assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6       # loss at the initial angles
     assert np.abs(out['history_params'] - ref['history_params'])[:, :2].max() < 3e-5           # = the first gradient (Adam's first step is lr * sign-like)

@@ -328,3 +328,45 @@ def test_integration_stub_from_the_document_runs():
     for s in range(10):
         assert (raw[s]['params'] == ref['params'][s]).all() and (raw[s]['regloss'] == ref['regloss'][s]).all()
     assert (cz == ref['cz']).all() and (passed == ref['passed']).all()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
+    """The N > 1 path end to end on one GPU: two worker processes (gloo rendezvous, both on cuda:0) run the real front
+    end - raw stage sharded by sample blocks, ONE gather, verification batch sharded too - and what rank 0 ends up with is
+    bit for bit what a single process computes: 37 samples (uneven shards 19 + 18), the same kernel variant either way."""
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), 'dist_worker.py')
+    S = 37
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    subprocess.check_call([sys.executable, worker, str(tmp_path / 'one.npz'), str(S)], env=env)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path / 'two.npz'), str(S)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)))
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    one, two = np.load(tmp_path / 'one.npz'), np.load(tmp_path / 'two.npz')
+    for k in one.files:
+        assert one[k].shape == two[k].shape and (one[k] == two[k]).all(), k
+    assert len(one['dec_cz']) >= 10 and one['passed'].sum() >= 20
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun starts two ranks itself (here both on the one GPU: CPF_ONE_DEVICE=1 ->
+    gloo) and reports n_gpus = 2 with the whole-job sample count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['CPF_ONE_DEVICE'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--samples-per-gpu', '256'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and '512 total' in line['config']['workload']
+    assert line['value'] > 0 and line['roofline']['bound'] == 'valu' and 'cpu_baseline' not in line
