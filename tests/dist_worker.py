@@ -19,8 +19,7 @@ def main(out_path, num_samples):
     if world > 1:
         torch.cuda.set_device(0)
         dist.init_process_group('gloo')
-    opts = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10, num_samples=num_samples, num_gd_iterations=400,
-                         num_gd_iterations_at_verification=600)
+    opts = StaticOptions(num_cp_gates=12, accepted_num_cz_gates=10, num_samples=num_samples, num_gd_iterations_at_verification=1500)
     syn = Synthesize([[0, 1], [1, 2]], target_unitary=workloads.CCZ, label='ccz')
     raw = syn._generate_raw(opts)
     with contextlib.redirect_stdout(io.StringIO()):
