@@ -183,3 +183,12 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     assert (os.stat(tmp_path / 'cache').st_mode & 0o077) == 0          # private directory
     r = run({'CPF_JIT_FORBID_COMPILE': '1'})                           # now served from the cache
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
+
+
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    """tools/host_sanitize.sh: the library's host code (validation, plan shape, kernel selection, JIT cache with a real
+    hipcc child process) built with -fsanitize=address,undefined and driven without a GPU: no finding, exit code 0."""
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'host_sanitize.sh'), str(tmp_path / 'san')], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert 'host sanitize driver: 0 failure(s)' in r.stdout and 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr

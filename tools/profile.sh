@@ -31,4 +31,6 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_AN
   (cd $root && rocprofv3 --pmc $grp --kernel-trace -d $pmc/$name -o p --output-format csv -- python3 tools/gpu.py one $cfg "" $tpmc > $pmc/$name.log 2>&1) || exit 1
   tail -1 $pmc/$name.log
 done
+# the summaries are written under profiles/ of THIS checkout: on a gpurun box only gpurun_out/ travels back, so run
+# `python tools/profile_summary.py <tag> <cfg>` again at home on the raw files merged into gpurun_out/
 cd $root && python3 tools/profile_summary.py $tag $cfg
