@@ -492,6 +492,28 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cn) {
     sn = __uint_as_float(__float_as_uint(s1) ^ (((unsigned)q & 2u) << 30));
     cn = __uint_as_float(__float_as_uint(c1) ^ ((((unsigned)q + 1u) & 2u) << 30));
 }
+// The same for two angles in one register pair: the reduction and both polynomials on v_pk_*_f32 (one instruction for both
+// angles), rounding / integer / select steps per half.  Per half the operations and their order are those of fast_sincos,
+// so the two give bit-identical results.
+__device__ __forceinline__ void fast_sincos2(f2 x, f2& sn, f2& cn) {
+    const f2 t = x * splat(0.636619772f);
+    const f2 k = f2{rintf(t.x), rintf(t.y)};
+    f2 r = pk_fma(-k, splat(1.57079637f), x);
+    r = pk_fma(-k, splat(-4.37113883e-8f), r);
+    r = pk_fma(-k, splat(-1.71512489e-15f), r);
+    const f2 z = r * r;
+    f2 ps = pk_fma(splat(-1.9515295891e-4f), z, splat(8.3321608736e-3f));
+    ps = pk_fma(ps, z, splat(-1.6666654611e-1f));
+    const f2 s0 = pk_fma(ps * z, r, r);
+    f2 pc = pk_fma(splat(2.443315711809948e-5f), z, splat(-1.388731625493765e-3f));
+    pc = pk_fma(pc, z, splat(4.166664568298827e-2f));
+    const f2 c0 = pk_fma(pc, z * z, pk_fma(splat(-0.5f), z, splat(1.f)));
+    const int qx = (int)k.x, qy = (int)k.y;
+    const bool ox = qx & 1, oy = qy & 1;
+    const float sx = ox ? c0.x : s0.x, cx = ox ? s0.x : c0.x, sy = oy ? c0.y : s0.y, cy = oy ? s0.y : c0.y;
+    sn = f2{__uint_as_float(__float_as_uint(sx) ^ (((unsigned)qx & 2u) << 30)), __uint_as_float(__float_as_uint(sy) ^ (((unsigned)qy & 2u) << 30))};
+    cn = f2{__uint_as_float(__float_as_uint(cx) ^ ((((unsigned)qx + 1u) & 2u) << 30)), __uint_as_float(__float_as_uint(cy) ^ ((((unsigned)qy + 1u) & 2u) << 30))};
+}
 // LDS copy of the piece table: 8 lower break points (pieces 1..8), then 9 x (slope, intercept); 28 floats.
 // Selecting among kernel-argument fields made hipcc select the field ADDRESS and issue a per-lane global
 // load from the kernarg segment, so the table is staged in LDS once and read with one per-lane ds_read.

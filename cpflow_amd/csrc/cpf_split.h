@@ -22,8 +22,16 @@
 namespace cpf {
 
 // number of blocks given to wave A: balances (surface ~ 1.5 blocks) + m against K - m, multiple of the layer length
+#ifndef CPF_CUT_EXTRA
+#define CPF_CUT_EXTRA 0          // A/B builds: whole layers moved from wave B's half to wave A's
+#endif
+// Since wave B owns every angle (its owner phase adds ~90 instructions to its step, wave A's has none) the balance point
+// sits later: same-box A/B on config 2 (K = 12, chain) 6.33 / 6.16 / 6.21 / 6.45 ms for 6 / 7 / 8 / 9 blocks in wave A; on
+// config 3's shape (K = 16, all-to-all, layers of 3) 6.87 ms at 6 blocks against 7.04 at 7 and 6.98 at 9.  Hence one more
+// layer for wave A where a layer is at most two blocks.
 __host__ __device__ constexpr int split_point(int K, int LL) {
-    int m = ((2 * K - 3 + 2 * LL) / (4 * LL)) * LL;          // LL * round((K - 1.5) / 2 / LL)
+    int m = ((2 * K - 3 + 2 * LL) / (4 * LL)) * LL + CPF_CUT_EXTRA * LL;          // LL * round((K - 1.5) / 2 / LL)
+    if (LL <= 2 && K >= 4 * LL) m += LL;
     if (m < LL) m = LL;
     const int top = ((K - 1) / LL) * LL;
     if (m > top) m = top;
@@ -570,7 +578,9 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
     // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a
     // same-box A/B (-DCPF_CUT_BALANCED builds it).
-#ifdef CPF_CUT_BALANCED
+#if defined(CPF_CUT_M)
+    constexpr int MC = KC > 0 ? CPF_CUT_M : 0, OFF = KC > 0 ? MC % LL : 0;          // A/B builds: this many blocks to wave A
+#elif defined(CPF_CUT_BALANCED)
     constexpr int MC = KC > 0 ? split_point_any(KC > 0 ? KC : 2) : 0, OFF = KC > 0 ? MC % LL : 0;
 #else
     constexpr int MC = KC > 0 ? split_point(KC > 0 ? KC : 2, LL) : 0, OFF = 0;
@@ -578,16 +588,16 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     const int m = KC > 0 ? MC : split_point(K, LL), kb = K - m;
     // The wave with the longer instruction stream sets the pace of every step and the other one has slack: while the
     // SIMDs are not saturated (a.prio, set by the host for S <= 8 x CUs) the longer one gets the higher issue
-    // priority (instruction counts as in split_point_any, + 90 for wave B's loss / penalty / best tracking).
+    // priority (instruction counts as in split_point_any, + 90 for wave B's loss / penalty / best tracking, + 90 for its owner phase).
     // Same box: config 2 S = 1024 6.70 -> 6.53 ms, S = 2048 12.05 -> 11.17 ms, but S = 4096 22.7 -> 23.9 and config 3's
     // shape at S = 4096 33.3 -> 35.3; with the priority on the SHORTER wave config 3's shape at S = 512 6.88 -> 8.18.
-    if (a.prio && (wave == 0) == (160 + 110 * m > 109 * kb + 90)) __builtin_amdgcn_s_setprio(3);
+    if (a.prio && (wave == 0) == (160 + 110 * m > 109 * kb + 180)) __builtin_amdgcn_s_setprio(3);
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
     float* gs = smem + Lds::slab(K);
-    float* red = smem + Lds::red(K);
+    (void)Lds::red(K);
     f2* xch = reinterpret_cast<f2*>(smem + Lds::xch(K)) + lane;                 // [0]: psi of wave A, [64]: W of wave B
     f2* ph = reinterpret_cast<f2*>(smem + Lds::phase(K)) + lane + (wave ? 64 * (m + 1) : 0);
     f2* sp = reinterpret_cast<f2*>(smem + Lds::states(K)) + lane + (wave ? 64 * (NI * m + 1) : 0);
@@ -603,55 +613,67 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     const f2 vt = {vt_.x, vt_.y};
     const int dst_lane = reduce8_dst_lane(lane);
 
-    // ---- owner state.  Owner slot o = (tid ^ 64) + 128 s; the K <= 64 CP angles come first, i.e. all in wave B
-    // (slot 0).  Wave A (surface gates + its half) is the critical path of every step and wave B has ~20 % slack
-    // (per-phase stamps), so everything that is not a sweep sits in wave B: the penalty of the CP angles, the loss,
-    // best-iterate tracking and the epilogue.
-    float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
-    int cs_off[PPT], g_off[PPT], pj[PPT];
-    bool valid[PPT], is_cp[PPT], frz[PPT];
+    // ---- owner state: ALL angles live in wave B, two per lane and register pair (slot o = lane + 64 (2 s + h), h = the
+    // half of pair s; the K <= 64 CP angles come first, i.e. in half 0 of pair 0).  Adam, the half-angle scaling and the
+    // sin / cos polynomials then run on v_pk_*_f32: one wave spends ~90 VALU operations per step on 2 x 64 angles where two
+    // waves used to spend 113 each on 64 angles apiece (18 % of the kernel's VALU instructions).  Wave A (surface gates +
+    // its half) is the critical path of every step and does none of this: the penalty of the CP angles, the loss,
+    // best-iterate tracking and the epilogue sit in wave B as well.
+    f2 th[PPT], mm[PPT], vv[PPT], hscale[PPT], nlr[PPT];
+    float psl = 0.f, pval = 0.f;
+    int cs_off[PPT][2], g_off[PPT][2], pj[PPT][2];
+    bool valid[PPT][2];
+    bool is_cp0 = false;
     penalty_table_init(smem, a, tid);
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
-        const int o = (tid ^ 64) + TH * s;
-        valid[s] = o < P;
-        int j = 0;
-        if (valid[s]) {
-            if (o < K) j = NS + NB * o + NB - 1;
-            else if (o - K < NS) j = o - K;
-            else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int o = lane + 64 * (2 * s + h);
+            valid[s][h] = wave != 0 && o < P;
+            int j = 0;
+            if (valid[s][h]) {
+                if (o < K) j = NS + NB * o + NB - 1;
+                else if (o - K < NS) j = o - K;
+                else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+            }
+            pj[s][h] = j;
+            const bool cp = valid[s][h] && a.pkind[j];
+            if (s == 0 && h == 0) is_cp0 = cp;
+            const bool frz = valid[s][h] && frozen && frozen[j];
+            if (j < NS) { cs_off[s][h] = Lds::SURF_CS + 2 * j; g_off[s][h] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
+            else {
+                const int bb = (j - NS) / NB, k = (j - NS) % NB;
+                cs_off[s][h] = Lds::BLK_CS + 16 * bb + 2 * k; g_off[s][h] = 32 * Lds::NBATCH + 32 * bb + 4 * k;
+            }
+            const float t0 = valid[s][h] ? init[j] : 0.f;
+            const float hs = cp ? 1.f : 0.5f;                               // CP gates take the full angle, rotations half of it
+            const float nl = (valid[s][h] && !frz) ? -a.lr : 0.f;           // frozen angles: the update is multiplied by -0
+            if (h == 0) { th[s].x = t0; hscale[s].x = hs; nlr[s].x = nl; } else { th[s].y = t0; hscale[s].y = hs; nlr[s].y = nl; }
+            if (valid[s][h]) { a.out_params[(s_idx * 2) * P + j] = t0; out_best[j] = t0; }
         }
-        pj[s] = j;
-        is_cp[s] = valid[s] && a.pkind[j];
-        frz[s] = valid[s] && frozen && frozen[j];
-        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
-        else {
-            const int b = (j - NS) / NB, k = (j - NS) % NB;
-            cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
-        }
-        th[s] = valid[s] ? init[j] : 0.f;
-        mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
-        if (valid[s]) { a.out_params[(s_idx * 2) * P + j] = th[s]; out_best[j] = th[s]; }
+        mm[s] = f2{0.f, 0.f}; vv[s] = f2{0.f, 0.f};
     }
     for (int b = tid; b < K; b += TH) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
     if (tid < 16) smem[Lds::ident(K) + tid] = (tid & 1) ? 0.f : 1.f;
     auto publish = [&](int s) __attribute__((always_inline)) {
-        const bool pen = a.use_reg && (K > TH * s) && is_cp[s];
+        const bool pen = s == 0 && a.use_reg && is_cp0;
         const bool lin = pen && a.pen_kind == 0;
         float x = 0.f;
         float2 si = make_float2(0.f, 0.f);
-        if (lin) { x = floor_mod_2pi(th[s]); si = penalty_lookup(smem, x); }
-        float sn, cn;
-        fast_sincos(is_cp[s] ? th[s] : 0.5f * th[s], sn, cn);
-        if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
-        if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
-        else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }
+        if (lin) { x = floor_mod_2pi(th[0].x); si = penalty_lookup(smem, x); }
+        f2 sn, cn;
+        fast_sincos2(th[s] * hscale[s], sn, cn);
+        if (valid[s][0]) *reinterpret_cast<float2*>(smem + cs_off[s][0]) = make_float2(cn.x, sn.x);
+        if (valid[s][1]) *reinterpret_cast<float2*>(smem + cs_off[s][1]) = make_float2(cn.y, sn.y);
+        if (lin) { pval = __fadd_rn(__fmul_rn(si.x, x), si.y); psl = a.r * si.x; }
+        else if (pen) { float sl; pval = penalty_lds(smem, a.pen_kind, th[0].x, sl); psl = a.r * sl; }
     };
-    // penalty sum of the CP angles (all owned by wave 0, slot 0): wave A reduces it at the top of its forward half
-    // (where it has slack against wave B) and hands it to wave B through LDS before the exchange barrier
     split_barrier();
+    if (wave != 0) {
 #pragma unroll
-    for (int s = 0; s < PPT; s++) publish(s);
+        for (int s = 0; s < PPT; s++) publish(s);
+    }
     split_barrier();
 
     float best = 0.f, first = 0.f;
@@ -683,7 +705,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             split_fwd<L, PL, LL, ROT, STORE, PS>(st, smem + Lds::BLK_CS, m, ph, sp);
             xch[0] = st.p[0];
         } else {
-            if (a.use_reg) pen_sum = wave_sum(pval[0]);        // CP angles: all owned by wave B, slot 0
+            if (a.use_reg) pen_sum = wave_sum(pval);           // CP angles: all owned by wave B, half 0 of pair 0
             st.p[0] = vt;
             split_inv<L, PL, LL, ROT, STORE, PS, OFF>(st, smem + Lds::BLK_CS + 16 * m, smem + Lds::ident(K), kb, ph, sp);
             xch[64] = st.p[0];
@@ -698,8 +720,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         const f2 tt = cmul_conj(st.p[0], w);          // T = sum psi conj(W)
         float tr = tt.x, ti = tt.y;
         wave_sum2(tr, ti);
-        // wave B alone turns T into the loss and tracks the best iterate; wave A needs only T (for the cotangent)
-        // and, at its owner phase, B's verdict on whether this iterate is the best so far (red[1])
+        // wave B alone turns T into the loss and tracks the best iterate (it owns every angle); wave A needs only T (for the
+        // cotangent)
         bool improved = false;
         if (wave != 0) {
             const float reg = a.use_reg ? a.r * pen_sum : 0.f;
@@ -708,16 +730,21 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             const float regloss = loss + reg;
             if (it == 0) { first = regloss; best = regloss; }
             else if (regloss < best) { best = regloss; improved = true; }
-            red[1] = improved ? 1.f : 0.f;
             if (improved) {
 #pragma unroll
-                for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
+                for (int s = 0; s < PPT; s++) {
+                    if (valid[s][0]) out_best[pj[s][0]] = th[s].x;
+                    if (valid[s][1]) out_best[pj[s][1]] = th[s].y;
+                }
             }
             if (a.hist_loss && lane == 0) a.hist_loss[s_idx * a.T + it] = regloss;
-        }
-        if (a.hist_params) {
+            if (a.hist_params) {
 #pragma unroll
-            for (int s = 0; s < PPT; s++) if (valid[s]) a.hist_params[(s_idx * a.T + it) * P + pj[s]] = th[s];
+                for (int s = 0; s < PPT; s++) {
+                    if (valid[s][0]) a.hist_params[(s_idx * a.T + it) * P + pj[s][0]] = th[s].x;
+                    if (valid[s][1]) a.hist_params[(s_idx * a.T + it) * P + pj[s][1]] = th[s].y;
+                }
+            }
         }
         if (a.T == 0) break;
         CPF_STAMP(2)                                  // loss phase done
@@ -764,24 +791,25 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         split_barrier();
         CPF_STAMP(4)                                  // waited for the other wave
 
-        // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty, owner threads
-        if (wave == 0 && red[1] != 0.f) {              // best iterate so far (decided by wave B): keep the pre-update angles
+        // ================= Adam (optax 0.1.1) + next step's (cos, sin) / penalty: wave B, two angles per lane and operation
+        if (wave != 0) {
+            const f2 ibc = f2{__builtin_amdgcn_rcpf(bc.x), __builtin_amdgcn_rcpf(bc.y)};
 #pragma unroll
-            for (int s = 0; s < PPT; s++) if (valid[s]) out_best[pj[s]] = th[s];
-        }
-        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
-#pragma unroll
-        for (int s = 0; s < PPT; s++) {
-            const float4 gp = *reinterpret_cast<const float4*>(gs + g_off[s]);
-            float g = (gp.x + gp.y) + (gp.z + gp.w);
-            if (a.use_reg && is_cp[s]) g += psl[s];
-            if (valid[s] && !frz[s]) {
-                const float mo = fmaf(a.b1, mm[s], a.omb1 * g);
-                const float v = fmaf(a.b2, vv[s], a.omb2 * (g * g));
+            for (int s = 0; s < PPT; s++) {
+                const float4 g0 = *reinterpret_cast<const float4*>(gs + g_off[s][0]);
+                const float4 g1 = *reinterpret_cast<const float4*>(gs + g_off[s][1]);
+                f2 g = f2{(g0.x + g0.y) + (g0.z + g0.w), (g1.x + g1.y) + (g1.z + g1.w)};
+                if (s == 0 && a.use_reg && is_cp0) g.x += psl;
+                // optax scale_by_adam: the same operations in the same order as the scalar form, per half
+                const f2 mo = pk_fma(splat(a.b1), mm[s], splat(a.omb1) * g);
+                const f2 v = pk_fma(splat(a.b2), vv[s], splat(a.omb2) * (g * g));
                 mm[s] = mo; vv[s] = v;
-                th[s] = fmaf(-a.lr, (mo * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[s]);
+                const f2 vh = v * splat(ibc.y);
+                const f2 den = f2{__builtin_amdgcn_sqrtf(vh.x), __builtin_amdgcn_sqrtf(vh.y)} + splat(a.eps);
+                const f2 upd = (mo * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                th[s] = pk_fma(nlr[s], upd, th[s]);
+                publish(s);
             }
-            publish(s);
         }
         CPF_STAMP(5)                                  // owner phase done
         split_barrier();
@@ -795,8 +823,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     if (wave != 0) {
         const int bi = (best < first) ? 1 : 0;
         float acc[3] = {0.f, 0.f, 0.f};
-        if (is_cp[0]) {
-            const int j = pj[0];
+        if (is_cp0) {
+            const int j = pj[0][0];
             const float t0 = a.out_params[(s_idx * 2) * P + j], t1 = out_best[j];
             float sl;
             if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
