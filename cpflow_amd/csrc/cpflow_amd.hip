@@ -18,7 +18,6 @@
 #include "cpf_blocks.h"
 #include "cpf_layered.h"
 #include "cpf_split.h"
-#include "cpf_split2.h"
 #include "cpf_dense.h"
 #include "cpf_dense_aot.h"
 #include "cpf_jit.h"
@@ -186,31 +185,6 @@ int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStre
     plan->variant = std::string("split/aot waves=2") + tag;
     return 0;
 }
-// Two samples per wave (cpf_split2.h): K-specialised, stored states only, i.e. while every workgroup of the launch (two
-// samples each) is resident at once.  RQ = the qubit kept in registers (the one most gates act on).
-bool split2_enabled() { const char* e = getenv("CPF_SPLIT2"); return e && e[0] == '1'; }   // opt-in: measured slower (one wave per SIMD at S = 1024)
-#ifndef CPF_SPLIT2_RQ
-#define CPF_SPLIT2_RQ 1
-#endif
-template <int ROT, int KC, int RQ, int... UD>
-bool try_split2(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    constexpr int NI = cpf::inner_gates<ROT>();
-    const size_t lds = (size_t)cpf::Split2Lds::total(KC, NI) * sizeof(float);
-    const int64_t wgs = (S + 1) / 2, per_cu = (wgs + plan->num_cu - 1) / plan->num_cu;
-    if (!split2_enabled() || a.loss_kind != 0 || S < 2 || lds > (size_t)plan->lds_per_cu || per_cu * (int64_t)lds > plan->lds_per_cu) return false;
-    auto kern = &cpf::k_cp_split2<ROT, KC, RQ, UD...>;
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { *rc = fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); return true; }
-    }
-    cpf::Split2Args sa{a, S};
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(128), lds, stream, sa);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { *rc = fail((int)e, "k_cp_split2: %s", hipGetErrorString(e)); return true; }
-    plan->variant = "split2/aot waves=2 states K";
-    *rc = 0;
-    return true;
-}
 template <int ROT, int PPT, int... UD>
 int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
     cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
@@ -219,15 +193,8 @@ int launch_layered3(const cpf_plan* plan_c, const cpf::KArgs& a, int K, int64_t 
     constexpr int LL = (int)sizeof...(UD) / 2;
     const bool kspec = kspec_enabled() && ROT == XYZ && PPT == 2 && ((LL == 2 && K == 12) || (LL == 3 && K == 16));
     if (want_split(plan, a, K, LL, ROT, S, kspec)) {
-        int rc2 = 0;
-        if constexpr (ROT == XYZ && PPT == 2 && LL == 2) {
-            if (kspec && try_split2<ROT, 12, CPF_SPLIT2_RQ, UD...>(plan, a, S, stream, &rc2)) return rc2;
-            if (kspec) return launch_split3<ROT, PPT / 2, 12, UD...>(plan, a, K, S, stream);
-        }
-        if constexpr (ROT == XYZ && PPT == 2 && LL == 3) {
-            if (kspec && try_split2<ROT, 16, CPF_SPLIT2_RQ, UD...>(plan, a, S, stream, &rc2)) return rc2;
-            if (kspec) return launch_split3<ROT, PPT / 2, 16, UD...>(plan, a, K, S, stream);
-        }
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 2) { if (kspec) return launch_split3<ROT, PPT / 2, 12, UD...>(plan, a, K, S, stream); }
+        if constexpr (ROT == XYZ && PPT == 2 && LL == 3) { if (kspec) return launch_split3<ROT, PPT / 2, 16, UD...>(plan, a, K, S, stream); }
         return launch_split3<ROT, PPT / 2, 0, UD...>(plan, a, K, S, stream);
     }
     const bool merge = cpf::layered_merge(3, 0, ROT);

@@ -66,13 +66,13 @@ def test_config3_toffoli_all_to_all_at_size():
     whole 4096 on one GPU, 2000 iterations; plus short-run oracle parity on the same target."""
     from cpflow_amd import workloads
     wl = workloads.CONFIGS['cfg3']
-    assert _short_run_parity(wl, S=5, T=14, tol=1e-5) in ('split2/aot waves=2 states K', 'split/aot waves=2 states K')
+    assert _short_run_parity(wl, S=5, T=14, tol=1e-5).startswith('split/aot waves=2')
     eng = _engine(wl)
     stats = []
     for S, first in ((512, 1024), (4096, 0)):          # rank 2's block of the 8-GPU run; all samples on one GPU
         init = eng.initial_angles(wl.seed, 4096, first, S)
         out = _np(eng.optimize(init))
-        assert eng.last_variant() in (('split2/aot waves=2 states K', 'split/aot waves=2 states K') if S == 512 else ('split/aot waves=2 K',)), eng.last_variant()
+        assert eng.last_variant() == 'split/aot waves=2' + (' states' if S == 512 else '') + ' K', eng.last_variant()
         _check_size_independent_properties(eng, init, out, S)
         ok = out['passed']
         assert ok.mean() > 0.5 and out['cz'][ok].min() <= 8          # Toffoli needs 6 CZ all-to-all; most starts converge

@@ -310,7 +310,6 @@ def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypat
     target = _rand_unitary(3, 22)
     T, S = 14, 5
     monkeypatch.setenv('CPF_SPLIT', '1')
-    monkeypatch.setenv('CPF_SPLIT2', '0')
     monkeypatch.setenv('CPF_PSTORE', pstore)
     monkeypatch.setenv('CPF_KSPEC', kspec)
     monkeypatch.setenv('CPF_JIT_K', kspec)
@@ -345,50 +344,6 @@ def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypat
     assert np.median(np.abs(outf['history_regloss'] - reff['history_loss'])[:, :10].max(axis=1)) < tol
 
 
-@pytest.mark.parametrize('layer,K', [([[0, 1], [1, 2]], 12), ([[0, 1], [0, 2], [1, 2]], 16)])
-@pytest.mark.parametrize('S', [5, 2, 64])
-def test_two_samples_per_wave_kernel_matches_oracle(layer, K, S, monkeypatch):
-    """cpf_split2.h: the two-ended kernel with two samples per wave and one row qubit in registers (the BASELINE
-    3-qubit shapes only).  Same checks as the one-sample form: float64 oracle over a short run with history, penalty on,
-    a frozen mask; odd batches (the last workgroup's second half is a masked copy), and agreement with cpf_split.h."""
-    target = _rand_unitary(3, 22)
-    T = 14
-    monkeypatch.setenv('CPF_SPLIT2', '1')
-    orc = Oracle(layer, K, target, 'xyz', num_gd_iterations=T, r=0.004)
-    eng = _engine(layer, K, target, 'xyz', num_gd_iterations=T, r=0.004)
-    init = orc.initial_angles(9, S)
-    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
-    assert eng.last_variant() == 'split2/aot waves=2 states K', eng.last_variant()
-    ref = orc.run(init, np.float64, keep_history=True)
-    tol = 1e-5
-    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < tol / 2
-    assert np.median(np.abs(out['history_regloss'] - ref['history_loss'])[:, :10].max(axis=1)) < tol
-    assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 5 * tol
-    assert np.abs(out['history_params'] - ref['history_params'])[:, :3].max() < 10 * tol
-    assert (out['params'][:, 0] == init).all()
-    assert np.abs(out['reg'][:, 0] - ref['reg'][:, 0]).max() < 1e-6
-    assert np.abs(out['reg'][:, 1] - ref['reg'][:, 1]).max() < tol / 10
-    assert np.abs(out['loss'] - ref['loss']).max() < 5 * tol and np.abs(out['regloss'] - ref['regloss']).max() < 5 * tol
-    assert (out['cz'] == ref['cz']).all() and (out['passed'] == ref['passed']).all()
-    frozen = np.zeros((S, orc.P), np.uint8)
-    frozen[:, ::3] = 1
-    frozen[S // 2:, 1] = 1                                # masks differ between the two samples of a wave
-    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen, keep_history=True).items()}
-    assert eng.last_variant().startswith('split2/')
-    hp = outf['history_params']
-    assert (hp[:, :, ::3] == init[:, None, ::3]).all() and (hp[:, -1, 2::3] != init[:, 2::3]).any()
-    assert (hp[S // 2:, :, 1] == init[S // 2:, None, 1]).all()
-    if S // 2 > 0:
-        assert (hp[:S // 2, -1, 1] != init[:S // 2, 1]).all()
-    # the one-sample-per-wave kernel on the same inputs: same arithmetic per gate in another order
-    monkeypatch.setenv('CPF_SPLIT2', '0')
-    eng1 = _engine(layer, K, target, 'xyz', num_gd_iterations=T, r=0.004)
-    out1 = {k: v.cpu().numpy() for k, v in eng1.optimize(init, keep_history=True).items()}
-    assert eng1.last_variant().startswith('split/')
-    assert np.abs(out1['history_regloss'] - out['history_regloss']).max() < 5 * tol
-    assert (out1['cz'] == out['cz']).all()
-
-
 def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
     """Same inputs through both 3-qubit kernels: identical first losses up to rounding, the same CZ counts on a
     short run, the same end-of-run statistics on config 2's shape; the relative-phase loss (non-linear
@@ -403,7 +358,7 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
         first = eng.optimize(init)['regloss'].cpu().numpy()[:, 0]
         eng = _engine(layer, K, ccz, 'xyz', num_gd_iterations=2000)
         out = {k: v.cpu().numpy() for k, v in eng.optimize(init).items()}
-        assert eng.last_variant().startswith(('split/', 'split2/') if split == '1' else 'layered/')
+        assert eng.last_variant().startswith('split/' if split == '1' else 'layered/')
         res[split] = (first, out)
     assert np.abs(res['0'][0] - res['1'][0]).max() < 1e-6
     a, b = res['0'][1], res['1'][1]
@@ -425,7 +380,6 @@ def test_issue_priority_does_not_change_results(monkeypatch):
     (cpf_split.h): a scheduling hint only - outputs are bit-identical with it on and off."""
     ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
     res = {}
-    monkeypatch.setenv('CPF_SPLIT2', '0')
     for prio in ('0', '1'):
         monkeypatch.setenv('CPF_PRIO', prio)
         eng = _engine([[0, 1], [1, 2]], 12, ccz, 'xyz', num_gd_iterations=300)
