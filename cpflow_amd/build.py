@@ -59,9 +59,12 @@ def precompile_shapes():
     conn5, chain5 = [[i, j] for i in range(5) for j in range(i + 1, 5)], [[i, i + 1] for i in range(4)]
     shapes = []
     for layer in (star4, conn4, chain4):
-        shapes += [(layer, rot, K, S) for rot in ('xyz', 'xz') for K in (14, 23, 29, 40) for S in (100, 2048)]
+        shapes += [(layer, rot, K, S, 'cp') for rot in ('xyz', 'xz') for K in (14, 23, 29, 40) for S in (100, 2048)]
     for layer in (conn5, chain5):
-        shapes += [(layer, rot, K, S) for rot in ('xyz', 'xz') for K in (30, 57, 86) for S in (200, 2000)]
+        shapes += [(layer, rot, K, S, 'cp') for rot in ('xyz', 'xz') for K in (30, 57, 86) for S in (200, 2000)]
+    # Ansatz(3, 'cz', fill_layers(connected_layer(3), k)).learn(...) with 1000 repeats (paper/results/local_minimums)
+    conn3, chain3 = [[0, 1], [0, 2], [1, 2]], [[0, 1], [1, 2]]
+    shapes += [(layer, 'xyz', K, 1000, 'cz') for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     return shapes
 
 
@@ -102,14 +105,14 @@ def precompile(shapes=None, workers=None, verbose=True):
     return sorted(seen)
 
 
-def _precompile_one(layer, rot, K, S):
+def _precompile_one(layer, rot, K, S, entangler='cp'):
     import ctypes as C
     import numpy as np
     from . import _ffi
     from .engine import placements_for, problem_struct
     n = max(max(p) for p in layer) + 1
     pl, target, rotb = placements_for(layer, K), np.ascontiguousarray(np.eye(1 << n, dtype=np.complex128)), rot.encode()
-    pb = problem_struct(n, pl, rotb, 'cp', 'hst', target)
+    pb = problem_struct(n, pl, rotb, entangler, 'hst', target)
     buf = C.create_string_buffer(4096)
     rc = _ffi.lib().cpf_jit_precompile(C.byref(pb), int(S), buf, 4096)
     if rc < 0:

@@ -210,6 +210,8 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     constexpr int UNR2 = (LL % 2 == 0) ? LL : 2 * LL;
     constexpr int UNR = (E == 1 && CPF_UNR6) ? ((UNR2 % 3 == 0) ? UNR2 : 3 * UNR2) : UNR2;
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
+    constexpr int ENT = rot_ent(ROT), NBP = NB - (ENT != 0 ? 1 : 0);          // parameters per block (CZ: the record's last slot is a constant)
+    static_assert(ENT == 0 || ENT == 1, "layered kernel: CP or CZ blocks");
     constexpr bool MERGE = layered_merge(NQ, LW, ROT);
     // MSTORE = 1: the forward pass keeps each run's phase in LDS (8 B per lane per block) for the backward pass;
     // MSTORE = 0: the backward pass rebuilds it (12 more ops per block, no LDS: better once LDS limits occupancy)
@@ -218,7 +220,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.P, K = (P - NS) / NB;
+    const int P = a.P, K = (P - NS) / NBP;
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
@@ -254,7 +256,8 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         valid[s] = o < P;
         int j = 0;
         if (valid[s]) {
-            if (o < K) j = NS + NB * o + NB - 1;
+            if constexpr (ENT != 0) j = o;                       // no CP angles: slots in parameter order
+            else if (o < K) j = NS + NB * o + NB - 1;
             else if (o - K < NS) j = o - K;
             else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
         }
@@ -263,14 +266,17 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         frz[s] = valid[s] && frozen && frozen[j];
         if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
         else {
-            const int b = (j - NS) / NB, k = (j - NS) % NB;
+            const int b = (j - NS) / NBP, k = (j - NS) % NBP;
             cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
         }
         th[s] = valid[s] ? init[j] : 0.f;
         mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
         if (valid[s]) { a.out_params[(s_idx * 2) * P + j] = th[s]; out_best[j] = th[s]; }
     }
-    for (int b = tid; b < K; b += THREADS) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
+    for (int b = tid; b < K; b += THREADS) {
+        smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f;
+        if constexpr (ENT != 0) { smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1)] = -1.f; smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1) + 1] = 0.f; }   // CZ = CP(pi), exactly
+    }
     auto publish = [&](int s) __attribute__((always_inline)) {
         // linear penalty: start the two LDS table lookups first, so they are in flight during sincos
         const bool pen = a.use_reg && (K > THREADS * s) && is_cp[s];

@@ -560,6 +560,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     constexpr int NQ = 3, TH = 128;
     constexpr int LL = sizeof...(UD) / 2;
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
+    constexpr int ENT = rot_ent(ROT), NBP = NB - (ENT != 0 ? 1 : 0);          // parameters per block (CZ: see cpf_blocks.h rot_ent)
+    static_assert(ENT == 0 || ENT == 1, "two-ended kernel: CP or CZ blocks");
     // MSTORE packs two things: bits 0-1 the storage mode (0 rebuild phases, 1 store phases, 2 store phases and
     // states), bits 2.. the block count K when the kernel is specialised on it (0 = K read from the plan): with K a
     // constant the sweeps are straight-line code - no prefetch-address clamps, tail guards or loop control
@@ -573,7 +575,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = KC > 0 ? NS + NB * KC : a.P, K = KC > 0 ? KC : (P - NS) / NB;
+    const int P = KC > 0 ? NS + NBP * KC : a.P, K = KC > 0 ? KC : (P - NS) / NBP;
     if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
     // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
     // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a
@@ -633,7 +635,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             valid[s][h] = wave != 0 && o < P;
             int j = 0;
             if (valid[s][h]) {
-                if (o < K) j = NS + NB * o + NB - 1;
+                if constexpr (ENT != 0) j = o;                   // no CP angles: slots in parameter order
+                else if (o < K) j = NS + NB * o + NB - 1;
                 else if (o - K < NS) j = o - K;
                 else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
             }
@@ -643,7 +646,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             const bool frz = valid[s][h] && frozen && frozen[j];
             if (j < NS) { cs_off[s][h] = Lds::SURF_CS + 2 * j; g_off[s][h] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
             else {
-                const int bb = (j - NS) / NB, k = (j - NS) % NB;
+                const int bb = (j - NS) / NBP, k = (j - NS) % NBP;
                 cs_off[s][h] = Lds::BLK_CS + 16 * bb + 2 * k; g_off[s][h] = 32 * Lds::NBATCH + 32 * bb + 4 * k;
             }
             const float t0 = valid[s][h] ? init[j] : 0.f;
@@ -654,7 +657,10 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         }
         mm[s] = f2{0.f, 0.f}; vv[s] = f2{0.f, 0.f};
     }
-    for (int b = tid; b < K; b += TH) { smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f; }
+    for (int b = tid; b < K; b += TH) {
+        smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f;
+        if constexpr (ENT != 0) { smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1)] = -1.f; smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1) + 1] = 0.f; }   // CZ = CP(pi), exactly
+    }
     if (tid < 16) smem[Lds::ident(K) + tid] = (tid & 1) ? 0.f : 1.f;
     auto publish = [&](int s) __attribute__((always_inline)) {
         const bool pen = s == 0 && a.use_reg && is_cp0;
