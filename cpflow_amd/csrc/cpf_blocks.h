@@ -13,9 +13,10 @@ namespace cpf {
 __host__ __device__ constexpr int rot_pack(int nr, int k0, int k1, int k2) { return nr | (k0 << 4) | (k1 << 8) | (k2 << 12); }
 __host__ __device__ constexpr int rot_nr(int rot) { return rot & 15; }
 __host__ __device__ constexpr int rot_kind(int rot, int i) { return (rot >> (4 + 4 * i)) & 15; }
-// bits 16-17: the block's entangler, 0 = CP(angle) (the block's last parameter), 1 = CZ (no parameter).  The layered
-// kernels treat CZ as a CP whose (cos, sin) record slot holds (-1, 0) for good: the sweeps are the same code, only the
-// parameter <-> record-slot map differs (2 NR parameters per block instead of 2 NR + 1).
+// bits 16-17: the block's entangler, 0 = CP(angle) (the block's last parameter), 1 = CZ, 2 = CX (no parameter).  The
+// layered kernels treat CZ as a CP whose (cos, sin) record slot holds (-1, 0) for good: the sweeps are the same code, only
+// the parameter <-> record-slot map differs (2 NR parameters per block instead of 2 NR + 1).  CX is a row permutation
+// (cpf_device.h cx_apply) in the gate-by-gate sweeps; it has no merged-diagonal or two-ended form.
 __host__ __device__ constexpr int rot_ent(int rot) { return (rot >> 16) & 3; }
 __host__ __device__ constexpr int rot_with_ent(int rot, int ent) { return (rot & 0xFFFF) | (ent << 16); }
 

@@ -72,7 +72,7 @@ __device__ __forceinline__ void gate_fence();
 // gradients share one product w = Im(conj(C) psi), and un-applying the run is one complex multiply by
 // conj(rho) for psi and one for C: 15 ops instead of 37 per block.
 __host__ __device__ constexpr bool layered_merge(int nq, int lw, int rot) {
-    return nq == 3 && lw == 0 && rot_nr(rot) >= 1 && rot_kind(rot, rot_nr(rot) - 1) == OP_RZ;
+    return nq == 3 && lw == 0 && rot_nr(rot) >= 1 && rot_kind(rot, rot_nr(rot) - 1) == OP_RZ && rot_ent(rot) != 2;   // a CX block is not diagonal
 }
 template <class L, int PUP, int PDN, int UP, int DN>
 __device__ __forceinline__ f2 diag_phase(const State<L>& st, float cu, float su, float cd, float sd, float cc, float sc) {
@@ -127,7 +127,8 @@ template <class L, int UP, int DN, int ROT>
 __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]) {
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1;
     constexpr int Q0 = UP < DN ? UP : DN, Q1 = UP < DN ? DN : UP;
-    cp_apply<L, Q0, Q1>(st.p, r[2 * (NB - 1)], r[2 * (NB - 1) + 1], st);
+    if constexpr (rot_ent(ROT) == 2) cx_apply<L, UP, DN>(st.p, st);            // gates.py:40-43: control = up, target = down
+    else cp_apply<L, Q0, Q1>(st.p, r[2 * (NB - 1)], r[2 * (NB - 1) + 1], st);
     gate_fence<L>();
 #pragma unroll
     for (int i = 0; i < NR; i++) {
@@ -169,10 +170,15 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
             d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
         }
     }
-    const float cc = r[2 * (NB - 1)], sc = r[2 * (NB - 1) + 1];
-    d[NB - 1] = cp_grad<L, Q0, Q1>(st);
-    cp_apply<L, Q0, Q1>(st.p, cc, -sc, st);
-    cp_apply<L, Q0, Q1>(st.c, cc, -sc, st);
+    if constexpr (rot_ent(ROT) == 2) {                   // CNOT: a row permutation, its own inverse, no parameter
+        cx_apply<L, UP, DN>(st.p, st);
+        cx_apply<L, UP, DN>(st.c, st);
+    } else {
+        const float cc = r[2 * (NB - 1)], sc = r[2 * (NB - 1) + 1];
+        d[NB - 1] = cp_grad<L, Q0, Q1>(st);
+        cp_apply<L, Q0, Q1>(st.p, cc, -sc, st);
+        cp_apply<L, Q0, Q1>(st.c, cc, -sc, st);
+    }
     gate_fence<L>();
 }
 
@@ -211,7 +217,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     constexpr int UNR = (E == 1 && CPF_UNR6) ? ((UNR2 % 3 == 0) ? UNR2 : 3 * UNR2) : UNR2;
     constexpr int NR = rot_nr(ROT), NB = 2 * NR + 1, NS = 3 * NQ;
     constexpr int ENT = rot_ent(ROT), NBP = NB - (ENT != 0 ? 1 : 0);          // parameters per block (CZ: the record's last slot is a constant)
-    static_assert(ENT == 0 || ENT == 1, "layered kernel: CP or CZ blocks");
+    static_assert(ENT >= 0 && ENT <= 2, "layered kernel: CP, CZ or CX blocks");
     constexpr bool MERGE = layered_merge(NQ, LW, ROT);
     // MSTORE = 1: the forward pass keeps each run's phase in LDS (8 B per lane per block) for the backward pass;
     // MSTORE = 0: the backward pass rebuilds it (12 more ops per block, no LDS: better once LDS limits occupancy)
@@ -220,7 +226,10 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.P, K = (P - NS) / NBP;
+    // NSP: surface PARAMETERS.  A 2-qubit problem runs as U (x) I on the 3-qubit kernel: the spectator's three surface
+    // record slots hold the identity (cos, sin) = (1, 0) and belong to no parameter.
+    const int NSP = 3 * a.n_actual;
+    const int P = a.P, K = (P - NSP) / NBP;
     const int64_t s_idx = blockIdx.x;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
@@ -257,16 +266,16 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         int j = 0;
         if (valid[s]) {
             if constexpr (ENT != 0) j = o;                       // no CP angles: slots in parameter order
-            else if (o < K) j = NS + NB * o + NB - 1;
-            else if (o - K < NS) j = o - K;
-            else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+            else if (o < K) j = NSP + NB * o + NB - 1;
+            else if (o - K < NSP) j = o - K;
+            else { const int q = o - K - NSP; j = NSP + NB * (q / (NB - 1)) + q % (NB - 1); }
         }
         pj[s] = j;
         is_cp[s] = valid[s] && a.pkind[j];
         frz[s] = valid[s] && frozen && frozen[j];
-        if (j < NS) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
+        if (j < NSP) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
         else {
-            const int b = (j - NS) / NBP, k = (j - NS) % NBP;
+            const int b = (j - NSP) / NBP, k = (j - NSP) % NBP;
             cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
         }
         th[s] = valid[s] ? init[j] : 0.f;
@@ -275,8 +284,9 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     }
     for (int b = tid; b < K; b += THREADS) {
         smem[Lds::BLK_CS + 16 * b + 14] = 0.f; smem[Lds::BLK_CS + 16 * b + 15] = 0.f;
-        if constexpr (ENT != 0) { smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1)] = -1.f; smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1) + 1] = 0.f; }   // CZ = CP(pi), exactly
+        if constexpr (ENT != 0) { smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1)] = -1.f; smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1) + 1] = 0.f; }   // CZ = CP(pi), exactly (unused by CX)
     }
+    for (int i = NSP + tid; i < NS; i += THREADS) { smem[Lds::SURF_CS + 2 * i] = 1.f; smem[Lds::SURF_CS + 2 * i + 1] = 0.f; }
     auto publish = [&](int s) __attribute__((always_inline)) {
         // linear penalty: start the two LDS table lookups first, so they are in flight during sincos
         const bool pen = a.use_reg && (K > THREADS * s) && is_cp[s];

@@ -575,7 +575,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = KC > 0 ? NS + NBP * KC : a.P, K = KC > 0 ? KC : (P - NS) / NBP;
+    const int NSP = KC > 0 ? NS : 3 * a.n_actual;            // surface parameters (2-qubit problems: see cpf_layered.h)
+    const int P = KC > 0 ? NS + NBP * KC : a.P, K = KC > 0 ? KC : (P - NSP) / NBP;
     if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
     // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
     // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a
@@ -636,17 +637,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             int j = 0;
             if (valid[s][h]) {
                 if constexpr (ENT != 0) j = o;                   // no CP angles: slots in parameter order
-                else if (o < K) j = NS + NB * o + NB - 1;
-                else if (o - K < NS) j = o - K;
-                else { const int q = o - K - NS; j = NS + NB * (q / (NB - 1)) + q % (NB - 1); }
+                else if (o < K) j = NSP + NB * o + NB - 1;
+                else if (o - K < NSP) j = o - K;
+                else { const int q = o - K - NSP; j = NSP + NB * (q / (NB - 1)) + q % (NB - 1); }
             }
             pj[s][h] = j;
             const bool cp = valid[s][h] && a.pkind[j];
             if (s == 0 && h == 0) is_cp0 = cp;
             const bool frz = valid[s][h] && frozen && frozen[j];
-            if (j < NS) { cs_off[s][h] = Lds::SURF_CS + 2 * j; g_off[s][h] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
+            if (j < NSP) { cs_off[s][h] = Lds::SURF_CS + 2 * j; g_off[s][h] = j < 8 ? 4 * j : 32 * Lds::NBATCH + 4 * 7; }   // ninth: block 0's spare slot
             else {
-                const int bb = (j - NS) / NBP, k = (j - NS) % NBP;
+                const int bb = (j - NSP) / NBP, k = (j - NSP) % NBP;
                 cs_off[s][h] = Lds::BLK_CS + 16 * bb + 2 * k; g_off[s][h] = 32 * Lds::NBATCH + 32 * bb + 4 * k;
             }
             const float t0 = valid[s][h] ? init[j] : 0.f;
@@ -662,6 +663,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         if constexpr (ENT != 0) { smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1)] = -1.f; smem[Lds::BLK_CS + 16 * b + 2 * (NB - 1) + 1] = 0.f; }   // CZ = CP(pi), exactly
     }
     if (tid < 16) smem[Lds::ident(K) + tid] = (tid & 1) ? 0.f : 1.f;
+    for (int i = NSP + tid; i < NS; i += TH) { smem[Lds::SURF_CS + 2 * i] = 1.f; smem[Lds::SURF_CS + 2 * i + 1] = 0.f; }
     auto publish = [&](int s) __attribute__((always_inline)) {
         const bool pen = s == 0 && a.use_reg && is_cp0;
         const bool lin = pen && a.pen_kind == 0;

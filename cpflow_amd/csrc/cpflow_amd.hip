@@ -371,15 +371,15 @@ int ppt_bucket(int ppt) {          // angles per owner thread, rounded up to a f
 std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, int lw, int64_t S) {
     std::vector<JitCandidate> out;
     plan->jit_note.clear();
-    // CP blocks, or CZ blocks as CP(pi) with a constant record slot (cpf_blocks.h rot_ent); CX blocks are not diagonal and
-    // stay on the generic kernel (dense blocks from 4 qubits up)
-    if (plan->n != plan->NQ || (plan->entangler != CPF_ENTANGLER_CP && plan->entangler != CPF_ENTANGLER_CZ) || plan->K < 1) return out;
+    // CP blocks; CZ blocks as CP(pi) with a constant record slot; CX blocks as a row permutation in the gate-by-gate sweeps
+    // (cpf_blocks.h rot_ent)
+    if ((plan->n != plan->NQ && plan->NQ != 3) || plan->K < 1) return out;     // n < NQ: a 2-qubit problem on the 3-qubit kernels
     if (plan->n_rot < 1 || plan->n_rot > 3 || plan->layer_ud.empty() || plan->layer_ud.size() > 32) return out;
     const int threads = 64 << lw, ppt = ppt_bucket((P + threads - 1) / threads);
     if (ppt > 12) { plan->jit_note = "too many angles per thread"; return out; }
     int kinds[3] = {0, 0, 0};
     for (int i = 0; i < plan->n_rot; i++) kinds[i] = plan->rot[i] == 'x' ? cpf::OP_RX : (plan->rot[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
-    const int rot_code = cpf::rot_with_ent(cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]), plan->entangler == CPF_ENTANGLER_CZ ? 1 : 0);
+    const int rot_code = cpf::rot_with_ent(cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]), plan->entangler == CPF_ENTANGLER_CZ ? 1 : (plan->entangler == CPF_ENTANGLER_CX ? 2 : 0));
     cpf::KArgs a{};
     a.loss_kind = loss_kind;
     const char* jk = getenv("CPF_JIT_K");                                        // opt-in: one build per block count

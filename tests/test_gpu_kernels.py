@@ -271,18 +271,22 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
     assert (out['cz'].cpu().numpy() == 0).all()
 
 
-@pytest.mark.parametrize('layer,K,rot,S,kind', [([[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'split/jit'), ([[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'layered/jit'),
-                                                ([[0, 1], [1, 2]], 3, 'xyz', 4, 'layered/jit'), ([[1, 2], [0, 1]], 9, 'xz', 6, 'split/jit'),
-                                                ([[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ([[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'layered/jit')])
-def test_cz_blocks_run_on_the_specialised_kernels(layer, K, rot, S, kind):
-    """Ansatz(..., 'cz') templates (main.py:72-73; the paper's local-minimum study, peppar.ipynb cells 14-17) use the
-    straight-line kernels: a CZ block is a CP block whose (cos, sin) record slot holds (-1, 0) and whose parameter list
-    is one shorter.  Short runs with history against the float64 oracle, a frozen mask, and the variant that ran."""
+@pytest.mark.parametrize('ent,layer,K,rot,S,kind', [
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'split/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'layered/jit'),
+    ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'layered/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'split/jit'),
+    ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'layered/jit'),
+    ('cx', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'layered/jit'), ('cx', [[2, 1], [0, 2]], 7, 'zy', 1500, 'layered/jit'),
+    ('cx', [[3, 0], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cx', [[0, 1], [1, 2], [2, 3], [3, 4]], 9, 'xz', 2000, 'layered/jit')])
+def test_cz_cx_blocks_run_on_the_specialised_kernels(ent, layer, K, rot, S, kind):
+    """Ansatz(..., 'cz' | 'cx') templates (main.py:72-73, gates.py:40-48; the paper's local-minimum study, peppar.ipynb
+    cells 14-17) use the straight-line kernels: a CZ block is a CP block whose (cos, sin) record slot holds (-1, 0) and
+    whose parameter list is one shorter; a CX block is a row permutation in the gate-by-gate sweeps.  Short runs with
+    history against the float64 oracle, a frozen mask, and the variant that ran."""
     n = max(max(p) for p in layer) + 1
     target = _rand_unitary(n, 31)
     T = 12
-    orc = Oracle(layer, K, target, rot, entangler='cz', num_gd_iterations=T)
-    eng = _engine(layer, K, target, rot, entangler='cz', num_gd_iterations=T, use_reg=False)
+    orc = Oracle(layer, K, target, rot, entangler=ent, num_gd_iterations=T)
+    eng = _engine(layer, K, target, rot, entangler=ent, num_gd_iterations=T, use_reg=False)
     assert eng.num_angles == orc.P == 3 * n + 2 * len(rot) * K
     theta = np.random.default_rng(K).uniform(0, 2 * np.pi, size=(S, orc.P)).astype(np.float32)
     out = {k: v.cpu().numpy() for k, v in eng.optimize(theta, keep_history=True).items()}
@@ -299,8 +303,34 @@ def test_cz_blocks_run_on_the_specialised_kernels(layer, K, rot, S, kind):
     outf = {k: v.cpu().numpy() for k, v in eng.optimize(theta, frozen=frozen, keep_history=True).items()}
     hp = outf['history_params']
     assert (hp[:, :, 1::4] == theta[:, None, 1::4]).all() and (hp[:, -1, 0::4] != theta[:, 0::4]).any()
-    reff = Oracle(layer, K, target, rot, entangler='cz', num_gd_iterations=T, frozen_mask=frozen[0]).run(theta[:m], np.float64, keep_history=True)
+    reff = Oracle(layer, K, target, rot, entangler=ent, num_gd_iterations=T, frozen_mask=frozen[0]).run(theta[:m], np.float64, keep_history=True)
     assert np.median(np.abs(outf['history_regloss'][:m] - reff['history_loss'])[:, :10].max(axis=1)) < 1e-5
+
+
+@pytest.mark.parametrize('ent,layer,K,rot,S,kind', [('cp', [[0, 1]], 3, 'xyz', 5, 'split/jit'), ('cp', [[1, 0]], 1, 'xz', 4, 'layered/jit'),
+                                                    ('cp', [[0, 1], [1, 0]], 4, 'zy', 3, 'layered/jit'), ('cz', [[0, 1]], 2, 'xyz', 2000, 'layered/jit'),
+                                                    ('cx', [[1, 0]], 3, 'xyz', 6, 'layered/jit')])
+def test_two_qubit_problems_run_on_the_three_qubit_kernels(ent, layer, K, rot, S, kind):
+    """A 2-qubit problem runs as U (x) I on the 3-qubit straight-line kernels: the spectator's surface record slots hold
+    the identity and belong to no parameter.  Penalty on, history and a frozen mask against the float64 oracle."""
+    target = _rand_unitary(2, 5)
+    T = 12
+    orc = Oracle(layer, K, target, rot, entangler=ent, num_gd_iterations=T, r=0.004)
+    eng = _engine(layer, K, target, rot, entangler=ent, num_gd_iterations=T, r=0.004)
+    assert eng.num_angles == orc.P == 6 + (2 * len(rot) + (ent == 'cp')) * K
+    theta = np.random.default_rng(3 * K).uniform(0, 2 * np.pi, size=(S, orc.P)).astype(np.float32)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(theta, keep_history=True).items()}
+    assert eng.last_variant().startswith(kind), eng.last_variant()
+    m = min(S, 8)
+    ref = orc.run(theta[:m], np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:m, 0] - ref['history_loss'][:, 0]).max() < 5e-6
+    assert np.abs(out['history_regloss'][:m] - ref['history_loss']).max() < 5e-5
+    assert np.abs(out['history_params'][:m] - ref['history_params'])[:, :3].max() < 1e-4
+    assert np.abs(out['reg'][:m] - ref['reg']).max() < 1e-6 and (out['cz'][:m] == ref['cz']).all()
+    frozen = np.zeros((S, orc.P), np.uint8)
+    frozen[:, 2::3] = 1
+    hp = eng.optimize(theta, frozen=frozen, keep_history=True)['history_params'].cpu().numpy()
+    assert (hp[:, :, 2::3] == theta[:, None, 2::3]).all() and (hp[:, -1, 0::3] != theta[:, 0::3]).any()
 
 
 @pytest.mark.parametrize('mstore', ['0', '1'])
