@@ -273,7 +273,10 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         pj[s] = j;
         is_cp[s] = valid[s] && a.pkind[j];
         frz[s] = valid[s] && frozen && frozen[j];
-        if (j < NSP) { cs_off[s] = Lds::SURF_CS + 2 * j; g_off[s] = 32 * (j / 8) + 4 * (j % 8); }
+        if (j < NSP) {                                       // surface gate 3 k + g sits on kernel qubit k; pgate finds it (qubits may be relabelled)
+            const int sj = valid[s] ? a.pgate[j] : 0;
+            cs_off[s] = Lds::SURF_CS + 2 * sj; g_off[s] = 32 * (sj / 8) + 4 * (sj % 8);
+        }
         else {
             const int b = (j - NSP) / NBP, k = (j - NSP) % NBP;
             cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;

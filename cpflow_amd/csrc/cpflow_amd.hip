@@ -55,8 +55,18 @@ struct cpf_plan {
     int n = 0, K = 0, n_rot = 0, nb = 0, P = 0, G = 0, T = 0, NQ = 0;
     int entangler = 0;
     std::string rot;
+    // A labelling = the names the kernels give the problem's qubits: [0] the problem's own, [1] most-used qubits last
+    // (fill_plan_shape; only 4 and 5 qubits).  Each has its own placements, gate program and target; a launch picks one
+    // (select_labelling) and the three vectors below are the picked labelling's.
+    struct Labelling {
+        std::vector<int> qperm, h_place, layer_ud;
+        DevBuf d_prog, d_pgate, d_target;
+    };
+    Labelling lab[2];
+    bool has_relabel = false;
     std::vector<int> layer_ud;       // (up, dn, up, dn, ...) of the shortest period of the placements
     std::vector<int> h_place;        // (up, dn) of every block
+    std::vector<int> qperm;          // kernel qubit of problem qubit q
     std::map<int, DevBuf> dense_tab; // per waves-per-sample variant of the dense kernel: its per-block table (cpf_dense.h)
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
@@ -64,7 +74,7 @@ struct cpf_plan {
     bool force_generic = false;      // CPF_FORCE_GENERIC=1: always use the generic per-gate kernel (A/B testing)
     std::vector<uint8_t> h_pkind;
     std::vector<int4> h_prog;
-    DevBuf d_prog, d_target, d_pkind, d_pgate, d_bias;
+    DevBuf d_pkind, d_bias;
     cpf::KArgs base{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -77,6 +87,18 @@ struct cpf_plan {
 };
 
 namespace {
+
+// labelling of a launch: relabelled for the optimiser on the one-wave layouts, the problem's own otherwise (and for
+// cpf_unitary_device, which returns U in the problem's labels)
+int labelling_for(const cpf_plan* plan, int mode, int lw) { return (plan->has_relabel && lw == 0 && mode != cpf::MODE_UNITARY) ? 1 : 0; }
+void select_labelling(cpf_plan* plan, int which) {
+    const cpf_plan::Labelling& lb = plan->lab[which];
+    plan->qperm = lb.qperm; plan->h_place = lb.h_place; plan->layer_ud = lb.layer_ud;
+}
+void apply_labelling(const cpf_plan* plan, int which, cpf::KArgs& a) {
+    const cpf_plan::Labelling& lb = plan->lab[which];
+    a.prog = lb.d_prog.as<int4>(); a.pgate = lb.d_pgate.as<int32_t>(); a.target = lb.d_target.as<float2>();
+}
 
 // Penalty table: the reference builds slopes / intercepts / break points from Python floats
 // (double) and they meet the float32 angle as float32 scalars (penalty.py:14-15, 44-71).
@@ -247,8 +269,8 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
         return false;
     constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
     const int ppt = (a.P + (64 << lw) - 1) / (64 << lw);
-    if (plan->NQ == 4 && lw == 0 && ppt == 3 && plan->layer_ud == std::vector<int>{0, 1, 1, 2, 2, 3}) {
-        *rc = launch_layered_aot<4, 0, XYZ, 3, 0, 1, 1, 2, 2, 3>(a, plan->K, S, stream);
+    if (plan->NQ == 4 && lw == 0 && ppt == 3 && plan->layer_ud == std::vector<int>{0, 2, 2, 3, 3, 1}) {      // chain_layer(4) relabelled (fill_plan_shape)
+        *rc = launch_layered_aot<4, 0, XYZ, 3, 0, 2, 2, 3, 3, 1>(a, plan->K, S, stream);
         return true;
     }
     if (plan->NQ == 6 && lw == 2 && ppt == 2 && plan->layer_ud == std::vector<int>{0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}) {
@@ -462,16 +484,22 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
 
 // Variant choice: one workgroup per sample; more waves per sample when there are too few
 // samples to fill 256 CUs x 4 SIMDs and the matrix is large enough to split by columns.
-int launch(const cpf_plan* plan_c, const cpf::KArgs& a, int64_t S, hipStream_t stream) {
+int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_t stream) {
     cpf_plan* plan = const_cast<cpf_plan*>(plan_c);
     if (S <= 0) return 0;
     if (S > 0x7fffffffLL) return fail(-21, "num_samples too large");
     int rc = 0;
+    const int lw = choose_lw(plan, S);
+    cpf::KArgs a = a_in;
+    {
+        const int which = labelling_for(plan, a.mode, lw);
+        select_labelling(plan, which);
+        apply_labelling(plan, which, a);
+    }
     // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
     // kernel; 3. generic per-gate kernel
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_dense(plan, a, S, stream, &rc)) return rc;
-    const int lw = choose_lw(plan, S);
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) return rc;
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
@@ -495,15 +523,40 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
     { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
-    pl->h_place.assign(pb->placements, pb->placements + 2 * (size_t)pl->K);
-    pl->layer_ud.clear();
-    for (int L = 1; L <= pl->K && pl->layer_ud.empty(); L++) {
-        bool periodic = true;
-        for (int b = L; b < pl->K && periodic; b++)
-            periodic = pb->placements[2 * b] == pb->placements[2 * (b % L)] &&
-                       pb->placements[2 * b + 1] == pb->placements[2 * (b % L) + 1];
-        if (periodic) pl->layer_ud.assign(pb->placements, pb->placements + 2 * L);
+    // Qubit relabelling (4 and 5 qubits, gate-by-gate kernel, one wave per sample).  That layout keeps the kernel's LAST
+    // row qubits in registers (cpf_device.h Lay: a rotation there is 2 packed instructions per amplitude, on a lane qubit 3,
+    // and a CP touches only the amplitudes whose register bits are set), so the qubits the template uses most go last:
+    // problem qubit q becomes kernel qubit qperm[q], stable by usage.  Everything that names a qubit (placements, the gate
+    // program, the rows and columns of the target) is relabelled; parameters keep their order (a surface gate's record slot
+    // is found through pgate).  chain_layer(4): (0, 1, 2, 3) -> (0, 2, 3, 1), config 4 56.5 -> 52.1 ms.  With four waves per
+    // sample every row qubit sits on lanes and the problem's own labels are kept (the 4-qubit star at 500 samples: 25.2 ms
+    // against 28.6 relabelled), hence the choice per launch.
+    pl->has_relabel = (pl->NQ == 4 || pl->NQ == 5) && pl->n == pl->NQ;
+    { const char* e = getenv("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
+    { const char* e = getenv("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
+    for (int which = 0; which < 2; which++) {
+        cpf_plan::Labelling& lb = pl->lab[which];
+        lb.qperm.resize((size_t)pl->n);
+        for (int q = 0; q < pl->n; q++) lb.qperm[q] = q;
+        if (which == 1 && pl->has_relabel) {
+            std::vector<int> use((size_t)pl->n, 0), order((size_t)pl->n);
+            for (int b = 0; b < pl->K; b++) { use[pb->placements[2 * b]]++; use[pb->placements[2 * b + 1]]++; }
+            for (int q = 0; q < pl->n; q++) order[q] = q;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return use[x] < use[y]; });
+            for (int k = 0; k < pl->n; k++) lb.qperm[order[k]] = k;
+        }
+        lb.h_place.resize(2 * (size_t)pl->K);
+        for (size_t i = 0; i < lb.h_place.size(); i++) lb.h_place[i] = lb.qperm[pb->placements[i]];
+        lb.layer_ud.clear();
+        for (int L = 1; L <= pl->K && lb.layer_ud.empty(); L++) {
+            bool periodic = true;
+            for (int b = L; b < pl->K && periodic; b++)
+                periodic = lb.h_place[2 * b] == lb.h_place[2 * (b % L)] && lb.h_place[2 * b + 1] == lb.h_place[2 * (b % L) + 1];
+            if (periodic) lb.layer_ud.assign(lb.h_place.begin(), lb.h_place.begin() + 2 * L);
+        }
     }
+    if (pl->has_relabel && pl->lab[1].qperm == pl->lab[0].qperm) pl->has_relabel = false;          // nothing to gain (e.g. a ring)
+    select_labelling(pl, 0);
 }
 
 }  // namespace
@@ -533,41 +586,63 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     // ---- gate program (main.py:106-146): surface Rz Rx Rz per qubit, then per block
     //      entangler followed by R_g(up) R_g(down) for each letter g (main.py:69-82)
     pl->h_pkind.assign(P, 0);
-    auto& prog = pl->h_prog;
-    for (int q = 0; q < n; q++) {
-        prog.push_back(make_int4(cpf::OP_RZ, q, 0, 3 * q + 0));
-        prog.push_back(make_int4(cpf::OP_RX, q, 0, 3 * q + 1));
-        prog.push_back(make_int4(cpf::OP_RZ, q, 0, 3 * q + 2));
-    }
-    for (int b = 0; b < pl->K; b++) {
-        const int up = pb->placements[2 * b], dn = pb->placements[2 * b + 1], base = 3 * n + pl->nb * b;
-        const int lo = up < dn ? up : dn, hi = up < dn ? dn : up;
-        if (pb->entangler == CPF_ENTANGLER_CP) {
-            prog.push_back(make_int4(cpf::OP_CP, lo, hi, base + pl->nb - 1));
-            pl->h_pkind[base + pl->nb - 1] = 1;
-        } else if (pb->entangler == CPF_ENTANGLER_CZ) {
-            prog.push_back(make_int4(cpf::OP_CZ, lo, hi, 0));
-        } else {
-            prog.push_back(make_int4(cpf::OP_CX, up, dn, 0));       // control = up, target = down
+    // perm[q] = the kernel's label of problem qubit q.  Surface gates are emitted in KERNEL qubit order, so that gate
+    // 3 k + g acts on kernel qubit k (the specialised kernels rely on it) while carrying the parameter 3 q + g of the problem
+    // qubit q it stands for; gates on different qubits commute.
+    auto build_prog = [&](const std::vector<int>& perm, std::vector<int4>& prog, std::vector<int32_t>& pgate) {
+        prog.clear();
+        std::vector<int> inv((size_t)n);
+        for (int q = 0; q < n; q++) inv[perm[q]] = q;
+        for (int k = 0; k < n; k++) {
+            const int q = inv[k];
+            prog.push_back(make_int4(cpf::OP_RZ, k, 0, 3 * q + 0));
+            prog.push_back(make_int4(cpf::OP_RX, k, 0, 3 * q + 1));
+            prog.push_back(make_int4(cpf::OP_RZ, k, 0, 3 * q + 2));
         }
-        for (int i = 0; i < pb->n_rot; i++) {
-            const int kind = pb->rot_axes[i] == 'x' ? cpf::OP_RX : (pb->rot_axes[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
-            prog.push_back(make_int4(kind, up, 0, base + 2 * i));
-            prog.push_back(make_int4(kind, dn, 0, base + 2 * i + 1));
+        for (int b = 0; b < pl->K; b++) {
+            const int up = perm[pb->placements[2 * b]], dn = perm[pb->placements[2 * b + 1]], base = 3 * n + pl->nb * b;
+            const int lo = up < dn ? up : dn, hi = up < dn ? dn : up;
+            if (pb->entangler == CPF_ENTANGLER_CP) {
+                prog.push_back(make_int4(cpf::OP_CP, lo, hi, base + pl->nb - 1));
+                pl->h_pkind[base + pl->nb - 1] = 1;
+            } else if (pb->entangler == CPF_ENTANGLER_CZ) {
+                prog.push_back(make_int4(cpf::OP_CZ, lo, hi, 0));
+            } else {
+                prog.push_back(make_int4(cpf::OP_CX, up, dn, 0));       // control = up, target = down
+            }
+            for (int i = 0; i < pb->n_rot; i++) {
+                const int kind = pb->rot_axes[i] == 'x' ? cpf::OP_RX : (pb->rot_axes[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
+                prog.push_back(make_int4(kind, up, 0, base + 2 * i));
+                prog.push_back(make_int4(kind, dn, 0, base + 2 * i + 1));
+            }
         }
-    }
-    pl->G = (int)prog.size();
-    std::vector<int32_t> pgate((size_t)P, 0);
-    for (int g = 0; g < pl->G; g++)
-        if (prog[g].x != cpf::OP_CZ && prog[g].x != cpf::OP_CX) pgate[prog[g].w] = g;
-    // ---- target, used as complex64, embedded as V (x) I when the kernel is wider than the problem
-    std::vector<float2> tgt((size_t)D * D, make_float2(0.f, 0.f));
+        pgate.assign((size_t)P, 0);
+        for (int g = 0; g < (int)prog.size(); g++)
+            if (prog[g].x != cpf::OP_CZ && prog[g].x != cpf::OP_CX) pgate[prog[g].w] = g;
+    };
     const int d = NQ - n;
-    for (int r = 0; r < N; r++)
-        for (int c = 0; c < N; c++)
-            for (int x = 0; x < (1 << d); x++)
-                tgt[(size_t)((r << d) | x) * D + ((c << d) | x)] =
-                    make_float2((float)pb->target[2 * ((size_t)r * N + c)], (float)pb->target[2 * ((size_t)r * N + c) + 1]);
+    std::vector<int4> prog[2];
+    std::vector<int32_t> pgate[2];
+    std::vector<float2> tgt[2];
+    for (int which = 0; which < (pl->has_relabel ? 2 : 1); which++) {
+        const std::vector<int>& perm = pl->lab[which].qperm;
+        build_prog(perm, prog[which], pgate[which]);
+        // target, used as complex64, rows and columns in the kernel's qubit labels, embedded as V (x) I when the kernel is
+        // wider than the problem
+        tgt[which].assign((size_t)D * D, make_float2(0.f, 0.f));
+        auto relabelled = [&](int r) {                        // qubit 0 = most significant bit (main.py:119)
+            int k = 0;
+            for (int q = 0; q < n; q++) k |= ((r >> (n - 1 - q)) & 1) << (n - 1 - perm[q]);
+            return k;
+        };
+        for (int r = 0; r < N; r++)
+            for (int c = 0; c < N; c++)
+                for (int x = 0; x < (1 << d); x++)
+                    tgt[which][(size_t)((relabelled(r) << d) | x) * D + ((relabelled(c) << d) | x)] =
+                        make_float2((float)pb->target[2 * ((size_t)r * N + c)], (float)pb->target[2 * ((size_t)r * N + c) + 1]);
+    }
+    pl->h_prog = prog[0];
+    pl->G = (int)prog[0].size();
 
     // ---- Adam bias corrections 1 - b^t in float32 (optax 0.1.1 bias_correction)
     std::vector<float2> bias((size_t)(pl->T > 0 ? pl->T : 1));
@@ -581,10 +656,12 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
         e = b.alloc(bytes);
         if (e == hipSuccess && bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
     };
-    up(pl->d_prog, prog.data(), prog.size() * sizeof(int4));
-    up(pl->d_target, tgt.data(), tgt.size() * sizeof(float2));
+    for (int which = 0; which < (pl->has_relabel ? 2 : 1); which++) {
+        up(pl->lab[which].d_prog, prog[which].data(), prog[which].size() * sizeof(int4));
+        up(pl->lab[which].d_pgate, pgate[which].data(), pgate[which].size() * sizeof(int32_t));
+        up(pl->lab[which].d_target, tgt[which].data(), tgt[which].size() * sizeof(float2));
+    }
     up(pl->d_pkind, pl->h_pkind.data(), (size_t)P);
-    up(pl->d_pgate, pgate.data(), pgate.size() * sizeof(int32_t));
     up(pl->d_bias, bias.data(), bias.size() * sizeof(float2));
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
@@ -598,11 +675,10 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) pl->lds_per_cu = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
 
     cpf::KArgs& a = pl->base;
-    a.prog = pl->d_prog.as<int4>(); a.G = pl->G; a.P = P; a.T = pl->T; a.mode = cpf::MODE_OPTIMIZE;
+    apply_labelling(pl, 0, a);
+    a.G = pl->G; a.P = P; a.T = pl->T; a.mode = cpf::MODE_OPTIMIZE;
     a.n_actual = n;
-    a.target = pl->d_target.as<float2>();
     a.pkind = pl->d_pkind.as<uint8_t>();
-    a.pgate = pl->d_pgate.as<int32_t>();
     a.bias = pl->d_bias.as<float2>();
     build_pieces(pb->penalty, a.pc);
     a.pen_kind = pb->penalty.kind;
@@ -755,7 +831,9 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
         if (buf && size) snprintf(buf, size, "%s", report.c_str());
         return built;
     }
-    for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, choose_lw(&pl, num_samples), num_samples)) {
+    const int lw = choose_lw(&pl, num_samples);
+    select_labelling(&pl, labelling_for(&pl, cpf::MODE_OPTIMIZE, lw));
+    for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {
         const cpf_jit::Code code = cpf_jit::build(c.spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", c.spec.body.c_str(), code.error.c_str());
         report += tag_with_backend(c.tag, code.backend) + (code.compiled ? " [built] " : " [cached] ") + c.spec.body + "\n";

@@ -333,6 +333,40 @@ def test_two_qubit_problems_run_on_the_three_qubit_kernels(ent, layer, K, rot, S
     assert (hp[:, :, 2::3] == theta[:, None, 2::3]).all() and (hp[:, -1, 0::3] != theta[:, 0::3]).any()
 
 
+@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [0, 2], [0, 3]], 7, 'xyz'), ([[0, 1], [1, 2], [2, 3], [3, 4]], 9, 'xz'),
+                                         ([[2, 1], [1, 3], [1, 0]], 6, 'zy')])
+def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch):
+    """With one wave per sample the 4- and 5-qubit kernels keep their last row qubits in registers, so the library relabels
+    the problem's qubits (most-used last; placements, gate program, target rows and columns) for those launches.
+    Parameters, the unitary entry point and every result stay in the problem's own labels: same history as the float64
+    oracle and as the un-relabelled launch (CPF_RELABEL=0) up to rounding, same unitary, same loss and gradient."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 17)
+    T, S = 12, 2100                                        # more samples than SIMDs: one wave per sample
+    orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.003)
+    theta = np.random.default_rng(2).uniform(0, 2 * np.pi, size=(S, orc.P)).astype(np.float32)
+    ref = orc.run(theta[:6], np.float64, keep_history=True)
+    res = {}
+    for relabel in ('1', '0'):
+        monkeypatch.setenv('CPF_RELABEL', relabel)
+        eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
+        out = {k: v.cpu().numpy() for k, v in eng.optimize(theta, keep_history=True).items()}
+        assert eng.last_variant().startswith('layered/jit') and eng.last_variant().endswith('waves=1'), eng.last_variant()
+        assert np.abs(out['history_regloss'][:6, 0] - ref['history_loss'][:, 0]).max() < 5e-6
+        assert np.abs(out['history_regloss'][:6] - ref['history_loss']).max() < 5e-5
+        assert np.abs(out['history_params'][:6] - ref['history_params'])[:, :3].max() < 1e-4
+        u = eng.unitary(theta[:3]).cpu().numpy()
+        for k in range(3):
+            assert np.abs(u[k] - orc.unitary(theta[k], np.float64)).max() < 5e-6
+        lg = eng.loss_and_grad(theta[:6])
+        rg = orc.loss_grad(theta[:6], np.float64)
+        assert np.abs(lg['grad'].cpu().numpy() - rg['grad']).max() < 1e-5
+        res[relabel] = out
+    assert np.abs(res['0']['history_regloss'][:, 0] - res['1']['history_regloss'][:, 0]).max() < 2e-6
+    assert np.median(np.abs(res['0']['history_regloss'] - res['1']['history_regloss']).max(axis=1)) < 1e-5
+    assert (res['0']['params'][:, 0] == res['1']['params'][:, 0]).all()
+
+
 @pytest.mark.parametrize('mstore', ['0', '1'])
 @pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 12, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 16, 'xyz'),
                                          ([[0, 1], [1, 2]], 7, 'xz'), ([[2, 0], [1, 2], [0, 1]], 5, 'xyz'),
