@@ -575,8 +575,8 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NSP = KC > 0 ? NS : 3 * a.n_actual;            // surface parameters (2-qubit problems: see cpf_layered.h)
-    const int P = KC > 0 ? NS + NBP * KC : a.P, K = KC > 0 ? KC : (P - NSP) / NBP;
+    const int NSP = 3 * a.n_actual;                          // surface parameters (2-qubit problems: see cpf_layered.h)
+    const int P = KC > 0 ? NSP + NBP * KC : a.P, K = KC > 0 ? KC : (P - NSP) / NBP;
     if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
     // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
     // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a

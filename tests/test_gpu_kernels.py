@@ -367,6 +367,21 @@ def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch)
     assert (res['0']['params'][:, 0] == res['1']['params'][:, 0]).all()
 
 
+def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch):
+    """CPF_JIT_K=1 (one build per block count) with a 2-qubit problem: the parameter count the kernel derives from its
+    compile-time K must use the problem's two qubits, not the kernel's three (found by tools/gpu.py fuzz)."""
+    layer, K, rot = [[0, 1]], 7, 'xyz'
+    target = _rand_unitary(2, 9)
+    orc = Oracle(layer, K, target, rot, entangler='cz', num_gd_iterations=8)
+    theta = np.random.default_rng(1).uniform(0, 2 * np.pi, size=(3, orc.P)).astype(np.float32)
+    ref = orc.run(theta, np.float64, keep_history=True)
+    monkeypatch.setenv('CPF_JIT_K', '1')
+    eng = _engine(layer, K, target, rot, entangler='cz', num_gd_iterations=8, use_reg=False)
+    out = eng.optimize(theta, keep_history=True)
+    assert eng.last_variant().startswith('split/jit') and eng.last_variant().endswith(' K'), eng.last_variant()
+    assert np.abs(out['history_regloss'].cpu().numpy() - ref['history_loss']).max() < 2e-5
+
+
 @pytest.mark.parametrize('mstore', ['0', '1'])
 @pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 12, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 16, 'xyz'),
                                          ([[0, 1], [1, 2]], 7, 'xz'), ([[2, 0], [1, 2], [0, 1]], 5, 'xyz'),
