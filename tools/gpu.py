@@ -163,21 +163,29 @@ def cmd_fuzz(args):
         T = 6
         S = 1100 if n in (4, 5) and rng.random() < 0.5 else 3          # 4 / 5 qubits: one wave per sample (relabelled qubits) or four
         r = float(rng.choice([0.0, 0.004]))
-        orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent)
+        loss = str(rng.choice(['hst', 'hst', 'state', 'relative_phase']))
+        if loss == 'state':
+            target = np.concatenate([target[:, :1], np.zeros((1 << n, (1 << n) - 1))], axis=1)
+        mask = (rng.random(3 * n + (2 * len(rot) + (ent == 'cp')) * K) < 0.3).astype(np.uint8) if rng.random() < 0.4 else None
+        orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent, loss_kind={'hst': 0, 'state': 1, 'relative_phase': 2}[loss],
+                     frozen_mask=mask)
         init = orc.initial_angles(int(rng.integers(1 << 20)), S)
         ref = orc.run(init[:3], np.float64, keep_history=True)
+        frozen = None if mask is None else np.broadcast_to(mask, (S, len(mask))).copy()
         for v in (VARIANTS if n == 3 else VARIANTS[:1]):
             for k in ('CPF_PSTORE', 'CPF_KSPEC', 'CPF_JIT_K', 'CPF_SPLIT'):
                 os.environ.pop(k, None)
             os.environ.update(v)
-            eng = TemplateEngine(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent)
-            out = {k: x.cpu().numpy() for k, x in eng.optimize(init, keep_history=True).items() if x is not None}
+            eng = TemplateEngine(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent, loss=loss)
+            out = {k: x.cpu().numpy() for k, x in eng.optimize(init, frozen=frozen, keep_history=True).items() if x is not None}
             e0 = np.abs(out['history_regloss'][:3, 0] - ref['history_loss'][:, 0]).max()
             eh = np.abs(out['history_regloss'][:3] - ref['history_loss']).max()
             ep = np.abs(out['history_params'][:3, :3] - ref['history_params'][:, :3]).max()
-            ok = e0 < 1e-5 and eh < 5e-5 and ep < 2e-4 and (out['cz'][:3] == ref['cz']).all()
+            # the state-preparation and relative-phase losses have null directions (e.g. the first Rz on |0>): their gradient is
+            # rounding noise, which Adam turns into steps of ~lr without touching the loss - compare angles for HST only
+            ok = e0 < 1e-5 and eh < 5e-5 and (ep < 2e-4 or loss != 'hst') and (out['cz'][:3] == ref['cz']).all()
             bad += not ok
-            print(f"{'ok ' if ok else 'BAD'} n={n} layer={layer} K={K} rot={rot} {ent} r={r} S={S} {v} [{eng.last_variant()}] first {e0:.1e} hist {eh:.1e} "
+            print(f"{'ok ' if ok else 'BAD'} n={n} layer={layer} K={K} rot={rot} {ent} {loss} r={r} S={S} frozen={mask is not None} {v} [{eng.last_variant()}] first {e0:.1e} hist {eh:.1e} "
                   f"params {ep:.1e}", flush=True)
     print('cases', N, 'failures', bad, 'time %.0fs' % (time.time() - t0))
     return 1 if bad else 0
