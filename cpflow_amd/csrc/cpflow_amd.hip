@@ -540,7 +540,7 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
         for (int q = 0; q < pl->n; q++) lb.qperm[q] = q;
         if (which == 1 && pl->has_relabel) {
             std::vector<int> use((size_t)pl->n, 0), order((size_t)pl->n);
-            for (int b = 0; b < pl->K; b++) { use[pb->placements[2 * b]]++; use[pb->placements[2 * b + 1]]++; }
+            for (int q : pl->lab[0].layer_ud) use[q]++;       // over one layer, so that the labels do not depend on the block count
             for (int q = 0; q < pl->n; q++) order[q] = q;
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return use[x] < use[y]; });
             for (int k = 0; k < pl->n; k++) lb.qperm[order[k]] = k;
