@@ -51,7 +51,8 @@ def launch_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():                # the one JSON line to stdout; library chatter (gloo) to stderr
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 
