@@ -144,14 +144,23 @@ __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]
         }
     }
 }
+// The gradient of a rotation can be read on either side of it (sigma commutes with its own rotation, so
+// Im(conj(C) sigma psi) is the same before and after the gate).  It is read BEFORE the gate, i.e. after un-applying it:
+// read after, the gradient and the un-application both need psi's partner amplitudes, the compiler shares them, and a
+// shared DPP read is no longer folded into its multiply (8 extra v_mov_b32_dpp per lane-qubit gate at 4 elements per lane).
+// Only there: for a register qubit (and with one element per lane) reading the gradient first keeps it off the
+// un-application's dependency chain, which matters when a SIMD holds a single wave (5-qubit chain at 1000 samples: 141 ms
+// against 148 with the late read everywhere).
 template <class L, int KIND, int Q>
 __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s) {
-    const float d = rot_grad<L, KIND, Q>(st);
-    gate_fence<L>();
+    constexpr bool LATE = L::row_on_lane(Q) && L::E > 1 && KIND != OP_RZ;
+    float d = 0.f;
+    if constexpr (!LATE) { d = rot_grad<L, KIND, Q>(st); gate_fence<L>(); }
     rot_apply<L, KIND, Q>(st.p, c, -s, st);
     gate_fence<L>();
     rot_apply<L, KIND, Q>(st.c, c, -s, st);
     gate_fence<L>();
+    if constexpr (LATE) { d = rot_grad<L, KIND, Q>(st); gate_fence<L>(); }
     return d;
 }
 template <class L, int UP, int DN, int ROT>
