@@ -156,27 +156,36 @@ __device__ __forceinline__ void lay_block_inv_inner(State<L>& st, const float (&
     }
 }
 
-// ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1
+// ---- wave B forward: blocks n-1 .. 0 un-applied from psi (= V on entry, W = H2^+ V on exit); n >= 1.
+// Two record buffers: block b (J = b mod UNR, UNR even) reads its own record from the buffer of J's parity and fetches
+// the previous block's record - its own successor's - into the other one at the START of the block, so that every record
+// is in flight for a whole block before it is used (also in the leading partial body: with K a compile-time constant
+// and fewer blocks than one body, that is the whole sweep).
 template <class L, class PL, int LL, int ROT, bool STORE, bool PS = false, int OFF = 0>
 __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const float* ident, int n, f2* ph, f2* sp = nullptr) {
     constexpr int UNR = SplitUnroll<LL>::UNR, NR = rot_nr(ROT), NB = 2 * NR + 1, NI = 2 * (NR - 1);
+    static_assert(UNR % 2 == 0, "record buffers alternate with the block index");
     float ra[16], rb[16];
     int b = n - 1;
-    load_rec(rec + 16 * b, ra);
     {
         const int jt = (n - 1) % UNR;
         static_for([&](auto jj) __attribute__((always_inline)) {
             constexpr int J = decltype(jj)::value, I = (J + OFF) % LL;
             if (J == jt) {
+                float (&cur)[16] = (J & 1) ? ra : rb;
+                load_rec(rec + 16 * b, cur);
                 const f2 rho = diag_phase<L, PL::v[2 * I], PL::v[2 * I + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
-                    st, ra[4 * (NR - 1)], ra[4 * (NR - 1) + 1], ra[4 * (NR - 1) + 2], ra[4 * (NR - 1) + 3], 1.f, 0.f);
+                    st, cur[4 * (NR - 1)], cur[4 * (NR - 1) + 1], cur[4 * (NR - 1) + 2], cur[4 * (NR - 1) + 3], 1.f, 0.f);
                 if constexpr (STORE) ph[64 * n] = rho;
                 phase_apply<L>(st.p[0], rho, true);
             }
         }, typename make_iseq<UNR>::type{});
     }
-    auto blk = [&](auto ii, auto ip, float (&cur)[16], float (&prv)[16]) __attribute__((always_inline)) {
-        constexpr int I = decltype(ii)::value, IP = decltype(ip)::value;
+    auto step = [&](auto jj) __attribute__((always_inline)) {
+        constexpr int J = UNR - 1 - decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
+        float (&cur)[16] = (J & 1) ? ra : rb;
+        float (&prv)[16] = (J & 1) ? rb : ra;
+        load_rec(b > 0 ? rec + 16 * (b - 1) : ident, prv);
         if constexpr (PS) lay_block_inv_inner_store<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur, sp + 64 * (NI * b + 1));
         else lay_block_inv_inner<L, PL::v[2 * I], PL::v[2 * I + 1], ROT>(st, cur);
         const f2 rho = diag_phase<L, PL::v[2 * IP], PL::v[2 * IP + 1], PL::v[2 * I], PL::v[2 * I + 1]>(
@@ -187,25 +196,9 @@ __device__ __forceinline__ void split_inv(State<L>& st, const float* rec, const 
         b--;
     };
     const int tail = n % UNR;
-    static_for([&](auto jj) __attribute__((always_inline)) {
-        constexpr int J = UNR - 1 - decltype(jj)::value, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
-        if (J < tail) {
-            load_rec(rec + 16 * b, ra);
-            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
-            blk(ic<I>{}, ic<IP>{}, ra, rb);
-        }
+    static_for([&](auto jj) __attribute__((always_inline)) {       // leading partial body: blocks n-1 .. n-tail
+        if (UNR - 1 - decltype(jj)::value < tail) step(jj);
     }, typename make_iseq<UNR>::type{});
-    if (b >= 0 && tail > 0) load_rec(rec + 16 * b, ra);
-    auto step = [&](auto jj) __attribute__((always_inline)) {
-        constexpr int JJ = decltype(jj)::value, J = UNR - 1 - JJ, I = (J + OFF) % LL, IP = (J + OFF + UNR - 1) % LL;
-        if constexpr ((JJ & 1) == 0) {
-            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, rb);
-            blk(ic<I>{}, ic<IP>{}, ra, rb);
-        } else {
-            load_rec(b > 0 ? rec + 16 * (b - 1) : ident, ra);
-            blk(ic<I>{}, ic<IP>{}, rb, ra);
-        }
-    };
     for (int full = n / UNR; full > 0; full--) static_for(step, typename make_iseq<UNR>::type{});
 }
 
