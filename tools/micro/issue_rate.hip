@@ -5,6 +5,7 @@
 //   fma       v_fma_f32                       pk        v_pk_fma_f32
 //   dppmul    v_mul_f32_dpp quad_perm         gate      the Rx gate of cpf_device.h: 2 x v_mul_f32_dpp + v_pk_fma_f32
 //   gate_reg  the register-resident Rx gate: v_pk_mul_f32 + v_pk_fma_f32 on an amplitude pair
+//   perm32/16 v_permlane32_swap / v_permlane16_swap on a register pair (each followed by nothing: the swap chain itself)
 // build: hipcc --offload-arch=gfx950 -O3 -o issue_rate issue_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,7 +15,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int CTRL> __device__ __forceinline__ float dppz(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
-enum { FMA = 0, PK = 1, DPPMUL = 2, GATE = 3, GATE_REG = 4 };
+enum { FMA = 0, PK = 1, DPPMUL = 2, GATE = 3, GATE_REG = 4, PERM32 = 5, PERM16 = 6 };
 template <int MODE> __host__ __device__ constexpr int insts_per_op() { return MODE == GATE ? 3 : (MODE == GATE_REG ? 4 : 1); }
 
 template <int MODE, int ILP>
@@ -33,6 +34,13 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, float* sink, in
                 if constexpr (MODE == FMA) x[i].x = fmaf(x[i].x, c, s);
                 else if constexpr (MODE == PK) x[i] = __builtin_elementwise_fma(x[i], cc, ss);
                 else if constexpr (MODE == DPPMUL) x[i].x = c * dppz<0xB1>(x[i].x);
+                else if constexpr (MODE == PERM32) {
+                    auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[i].x), __float_as_uint(x[i].y), false, false);
+                    x[i].x = __uint_as_float(r2[0]); x[i].y = __uint_as_float(r2[1]);
+                } else if constexpr (MODE == PERM16) {
+                    auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[i].x), __float_as_uint(x[i].y), false, false);
+                    x[i].x = __uint_as_float(r2[0]); x[i].y = __uint_as_float(r2[1]);
+                }
                 else if constexpr (MODE == GATE) {
                     f2 t;
                     t.x = s * dppz<0xB1>(x[i].y);
@@ -75,6 +83,6 @@ template <int MODE> void sweep(const char* name) {
     for (int w : {1, 2, 4, 8}) { run<MODE, 1>(name, w); run<MODE, 2>(name, w); run<MODE, 4>(name, w); run<MODE, 8>(name, w); }
 }
 int main() {
-    sweep<FMA>("fma"); sweep<PK>("pk"); sweep<DPPMUL>("dppmul"); sweep<GATE>("gate"); sweep<GATE_REG>("gate_reg");
+    sweep<FMA>("fma"); sweep<PK>("pk"); sweep<DPPMUL>("dppmul"); sweep<PERM32>("perm32"); sweep<PERM16>("perm16"); sweep<GATE>("gate"); sweep<GATE_REG>("gate_reg");
     return 0;
 }
