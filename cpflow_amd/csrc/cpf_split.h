@@ -820,6 +820,17 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     if (s_idx == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 * wave + k] = (float)stamp_sum[k];
 #endif
 
+#ifdef CPF_HWID
+    // diagnostics build (tools/micro/hwid.py, keep_history, T >= 4): HW_ID / XCC_ID of the sample's two waves in place of
+    // the first four entries of its loss history
+    if (a.hist_loss && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.hist_loss[s_idx * a.T + 2 * wave] = (float)(hw & 0xffff);
+        a.hist_loss[s_idx * a.T + 2 * wave + 1] = (float)(xcc & 0xf);
+    }
+#endif
     // ================= epilogue (optimization.py:365-370, cp_utils.py:144-164): CP owners, first and best all sit in wave B
     if (wave != 0) {
         const int bi = (best < first) ? 1 : 0;
