@@ -78,6 +78,7 @@ struct KArgs {
     float* out_grad;           // MODE_LOSS_GRAD: [S][P] or null
     float2* out_U;             // MODE_UNITARY: [S][N][N]
     int prio;                  // two-ended kernel: raise the longer wave's issue priority (launches that leave SIMDs unsaturated)
+    int nsamples;              // samples of this launch (kernels with several samples per workgroup mask the tail)
 };
 
 // ------------------------------------------------------------------ layout

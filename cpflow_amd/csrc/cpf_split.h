@@ -559,18 +559,23 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     // states), bits 2.. the block count K when the kernel is specialised on it (0 = K read from the plan): with K a
     // constant the sweeps are straight-line code - no prefetch-address clamps, tail guards or loop control
     // (~400 scalar / branch instructions per sample-step at config 2) and LDS addresses become immediates.
-    constexpr int MS = MSTORE & 3, KC = MSTORE >> 2;
+    // bit 16: TWO wave pairs (samples) per workgroup.  The hardware starts consecutive two-wave workgroups one SIMD apart,
+    // (0, 1) then (1, 2), so with two or three workgroups per CU some SIMDs hold two waves and some none (read back through
+    // HW_ID: at 512 samples 256 of the 1024 SIMDs idle and 256 doubly booked); four waves per workgroup land on the four SIMDs.
+    constexpr int MS = MSTORE & 3, KC = (MSTORE >> 2) & 0xFFF, PAIRS = ((MSTORE >> 16) & 1) + 1;
     constexpr bool STORE = MS != 0;
     constexpr bool PS = MS == 2;                              // stored-state gradient halves
     constexpr int NI = 2 * (NR - 1);
     static_assert(layered_merge(3, 0, ROT), "two-ended kernel: rotation string must end in 'z'");
     static_assert(L::E == 1, "two-ended kernel: one element per lane");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+    const int tid = threadIdx.x & 127, lane = tid & 63;     // thread of its wave pair
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = PAIRS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7) : 0;
     const int NSP = 3 * a.n_actual;                          // surface parameters (2-qubit problems: see cpf_layered.h)
     const int P = KC > 0 ? NSP + NBP * KC : a.P, K = KC > 0 ? KC : (P - NSP) / NBP;
     if (KC > 0 && a.P != P) return;                          // host error: plan and specialisation disagree
+    float* smem = smem_wg + pair * Lds::total(K, MS, NI);     // every wave pair has its own copy of the whole map
     // The cut stays on a layer boundary.  An instruction-count-balanced cut (5 of 12, 7 of 16; wave B's pair indices
     // then carry the offset OFF = m mod LL) measured 1 % slower on config 2 and equal on config 3's shape in a
     // same-box A/B (-DCPF_CUT_BALANCED builds it).
@@ -579,7 +584,11 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
 #elif defined(CPF_CUT_BALANCED)
     constexpr int MC = KC > 0 ? split_point_any(KC > 0 ? KC : 2) : 0, OFF = KC > 0 ? MC % LL : 0;
 #else
-    constexpr int MC = KC > 0 ? split_point(KC > 0 ? KC : 2, LL) : 0, OFF = 0;
+    // bit 17 of MSTORE: the cut for launches that leave at most one wave on a SIMD (K / 2: the step is then the longer
+    // wave's chain and nothing else; measured best at 256 / 512 samples, config 3's shape 7 / 8 / 9 of 16: 6.26 / 6.03 /
+    // 6.44 ms, config 2's shape 6 / 7 of 12: 5.09 / 5.52 ms); otherwise the cut measured best with two waves per SIMD
+    constexpr bool LONE = KC > 0 && ((MSTORE >> 17) & 1) != 0;
+    constexpr int MC = KC > 0 ? (LONE ? KC / 2 : split_point(KC > 0 ? KC : 2, LL)) : 0, OFF = KC > 0 ? MC % LL : 0;
 #endif
     const int m = KC > 0 ? MC : split_point(K, LL), kb = K - m;
     // The wave with the longer instruction stream sets the pace of every step and the other one has slack: while the
@@ -588,7 +597,11 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     // Same box: config 2 S = 1024 6.70 -> 6.53 ms, S = 2048 12.05 -> 11.17 ms, but S = 4096 22.7 -> 23.9 and config 3's
     // shape at S = 4096 33.3 -> 35.3; with the priority on the SHORTER wave config 3's shape at S = 512 6.88 -> 8.18.
     if (a.prio && (wave == 0) == (160 + 110 * m > 109 * kb + 180)) __builtin_amdgcn_s_setprio(3);
-    const int64_t s_idx = blockIdx.x;
+    // an odd batch: the last workgroup's second pair runs a copy of the last sample (it must meet the same barriers) and
+    // writes nothing
+    const int64_t s_raw = (int64_t)blockIdx.x * PAIRS + pair;
+    const bool vs = PAIRS == 1 || s_raw < a.nsamples;
+    const int64_t s_idx = vs ? s_raw : (int64_t)a.nsamples - 1;
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
@@ -647,7 +660,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             const float hs = cp ? 1.f : 0.5f;                               // CP gates take the full angle, rotations half of it
             const float nl = (valid[s][h] && !frz) ? -a.lr : 0.f;           // frozen angles: the update is multiplied by -0
             if (h == 0) { th[s].x = t0; hscale[s].x = hs; nlr[s].x = nl; } else { th[s].y = t0; hscale[s].y = hs; nlr[s].y = nl; }
-            if (valid[s][h]) { a.out_params[(s_idx * 2) * P + j] = t0; out_best[j] = t0; }
+            if (valid[s][h] && vs) { a.out_params[(s_idx * 2) * P + j] = t0; out_best[j] = t0; }
         }
         mm[s] = f2{0.f, 0.f}; vv[s] = f2{0.f, 0.f};
     }
@@ -731,15 +744,15 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
             const float regloss = loss + reg;
             if (it == 0) { first = regloss; best = regloss; }
             else if (regloss < best) { best = regloss; improved = true; }
-            if (improved) {
+            if (improved && vs) {
 #pragma unroll
                 for (int s = 0; s < PPT; s++) {
                     if (valid[s][0]) out_best[pj[s][0]] = th[s].x;
                     if (valid[s][1]) out_best[pj[s][1]] = th[s].y;
                 }
             }
-            if (a.hist_loss && lane == 0) a.hist_loss[s_idx * a.T + it] = regloss;
-            if (a.hist_params) {
+            if (a.hist_loss && lane == 0 && vs) a.hist_loss[s_idx * a.T + it] = regloss;
+            if (a.hist_params && vs) {
 #pragma unroll
                 for (int s = 0; s < PPT; s++) {
                     if (valid[s][0]) a.hist_params[(s_idx * a.T + it) * P + pj[s][0]] = th[s].x;
@@ -844,7 +857,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
-        if (lane == 0) {
+        if (lane == 0 && vs) {
             const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
             const float l0 = first - reg0, l1 = best - reg1;
             a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
@@ -857,7 +870,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
 }
 
 template <int ROT, int PPT, int MSTORE, int... UD>
-__global__ __launch_bounds__(128, 1) void k_cp_split(const KArgs a) {
+__global__ __launch_bounds__(128 * (((MSTORE >> 16) & 1) + 1), 1) void k_cp_split(const KArgs a) {
     split_body<ROT, PPT, MSTORE, UD...>(a);
 }
 

@@ -193,6 +193,32 @@ template <int ROT, int PPT, int KC, int... UD>
 int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
     const size_t lds2 = (size_t)cpf::SplitLds::total(K, 2, cpf::inner_gates<ROT>()) * sizeof(float);
     const char* tag = KC ? " K" : "";
+    if constexpr (cpf::rot_nr(ROT) >= 2 && KC > 0) {
+        // Launches that leave at most one wave of this kernel on a SIMD (one or two samples per CU): the cut that balances the
+        // two waves' chains (MSTORE bit 17), and with two samples per CU both in ONE workgroup (bit 16) - consecutive two-wave
+        // workgroups start one SIMD apart, (0, 1) then (1, 2), which books one SIMD twice and leaves one idle
+        // (tools/micro/hwid.py).  Config 3's share (512 samples): 6.88 -> 6.03 ms; config 2's shape 5.84 -> 5.09 (512
+        // samples), 5.63 -> 4.83 (256).  With four samples per CU neither helps (6.03 -> 6.35 ms at config 2).
+        const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
+        int pairs = per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0);
+        { const char* e = getenv("CPF_PAIRS"); if (e) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
+        if (pairs == 2 && (S < 2 || ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * lds2) > plan->lds_per_cu)) pairs = 0;
+        if (pairs == 1 && !states_fit(plan, S, ROT, lds2)) pairs = 0;
+        if (pairs == 2) {
+            auto kern = &cpf::k_cp_split<ROT, PPT, 2 + 4 * KC + (3 << 16), UD...>;
+            CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds2)));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((S + 1) / 2)), dim3(256), 2 * lds2, stream, a);
+            CPF_HIP(hipGetLastError());
+            plan->variant = "split/aot waves=2 states K pairs=2";
+            return 0;
+        }
+        if (pairs == 1) {
+            hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT, 2 + 4 * KC + (2 << 16), UD...>), dim3((unsigned)S), dim3(128), lds2, stream, a);
+            CPF_HIP(hipGetLastError());
+            plan->variant = "split/aot waves=2 states K lone";
+            return 0;
+        }
+    }
     if constexpr (cpf::rot_nr(ROT) >= 2) {
         if (states_fit(plan, S, ROT, lds2)) {
             hipLaunchKernelGGL((cpf::k_cp_split<ROT, PPT, 2 + 4 * KC, UD...>), dim3((unsigned)S), dim3(128), lds2, stream, a);
@@ -491,6 +517,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     int rc = 0;
     const int lw = choose_lw(plan, S);
     cpf::KArgs a = a_in;
+    a.nsamples = (int)S;
     {
         const int which = labelling_for(plan, a.mode, lw);
         select_labelling(plan, which);

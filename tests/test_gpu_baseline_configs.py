@@ -72,7 +72,8 @@ def test_config3_toffoli_all_to_all_at_size():
     for S, first in ((512, 1024), (4096, 0)):          # rank 2's block of the 8-GPU run; all samples on one GPU
         init = eng.initial_angles(wl.seed, 4096, first, S)
         out = _np(eng.optimize(init))
-        assert eng.last_variant() == 'split/aot waves=2' + (' states' if S == 512 else '') + ' K', eng.last_variant()
+        # 512 samples = two per CU: both in one workgroup (even SIMD placement) with the cut for one wave per SIMD
+        assert eng.last_variant() == ('split/aot waves=2 states K pairs=2' if S == 512 else 'split/aot waves=2 K'), eng.last_variant()
         _check_size_independent_properties(eng, init, out, S)
         ok = out['passed']
         assert ok.mean() > 0.5 and out['cz'][ok].min() <= 8          # Toffoli needs 6 CZ all-to-all; most starts converge
