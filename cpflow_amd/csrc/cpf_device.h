@@ -79,6 +79,7 @@ struct KArgs {
     float2* out_U;             // MODE_UNITARY: [S][N][N]
     int prio;                  // two-ended kernel: raise the longer wave's issue priority (launches that leave SIMDs unsaturated)
     int nsamples;              // samples of this launch (kernels with several samples per workgroup mask the tail)
+    int lone;                  // two-ended kernel, K from the plan: at most one sample per CU - balance the two waves' chains
 };
 
 // ------------------------------------------------------------------ layout

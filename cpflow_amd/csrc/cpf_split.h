@@ -38,6 +38,16 @@ __host__ __device__ constexpr int split_point(int K, int LL) {
     return m < 0 ? 0 : m;
 }
 __host__ __device__ constexpr bool split_supported(int K, int LL) { return K >= 2 * LL && K >= 2 && K <= 64; }
+// the cut for launches that leave at most one wave on a SIMD (KArgs::lone): the step is then the longer wave's chain, so
+// the two waves get the same number of blocks, rounded DOWN to a layer boundary (wave A also has the surface gates).  K from
+// the plan, same box: config 2's shape 7.61 -> 6.67 ms at 100 and 256 samples (6 of 12 instead of 8); config 3's shape keeps
+// 6 of 16 (9 measured 8.60 against 7.81 ms)
+__host__ __device__ constexpr int lone_point(int K, int LL) {
+    int m = (K / (2 * LL)) * LL;
+    if (m < LL) m = LL;
+    const int top = ((K - 1) / LL) * LL;
+    return m > top ? top : m;
+}
 // With K a compile-time constant the cut need not fall on a layer boundary (wave B's pair indices carry the offset
 // m mod LL).  Instruction counts of the packed stored-state sweeps: wave A = 160 (surface gates, both directions)
 // + 110 per block, wave B = 109 per block + 90 (loss, penalty, best tracking)  ->  m = (109 K - 70) / 219 rounded:
@@ -590,7 +600,7 @@ __device__ __forceinline__ void split_body(const KArgs& a) {
     constexpr bool LONE = KC > 0 && ((MSTORE >> 17) & 1) != 0;
     constexpr int MC = KC > 0 ? (LONE ? KC / 2 : split_point(KC > 0 ? KC : 2, LL)) : 0, OFF = KC > 0 ? MC % LL : 0;
 #endif
-    const int m = KC > 0 ? MC : split_point(K, LL), kb = K - m;
+    const int m = KC > 0 ? MC : (a.lone ? lone_point(K, LL) : split_point(K, LL)), kb = K - m;
     // The wave with the longer instruction stream sets the pace of every step and the other one has slack: while the
     // SIMDs are not saturated (a.prio, set by the host for S <= 8 x CUs) the longer one gets the higher issue
     // priority (instruction counts as in split_point_any, + 90 for wave B's loss / penalty / best tracking, + 90 for its owner phase).

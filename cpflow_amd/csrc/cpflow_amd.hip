@@ -518,6 +518,8 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     const int lw = choose_lw(plan, S);
     cpf::KArgs a = a_in;
     a.nsamples = (int)S;
+    a.lone = S <= plan->num_cu ? 1 : 0;
+    { const char* e = getenv("CPF_LONE"); if (e) a.lone = e[0] == '1'; }      // A/B and tests
     {
         const int which = labelling_for(plan, a.mode, lw);
         select_labelling(plan, which);
