@@ -79,15 +79,22 @@ struct DLay {
 // ---- host side: the per-block table ----------------------------------------------------------------------------
 // up, dn: the placement (up = first qubit).  Lane qubits of the pair are exchanged with the lowest register qubits
 // outside the pair.
+// avoid: qubits not to exchange with (bit mask), when enough other register qubits exist.
 template <class L>
-__host__ __device__ constexpr DenseBlock dense_block_entry(int up, int dn, int first_gate) {
+__host__ __device__ constexpr DenseBlock dense_block_entry(int up, int dn, int first_gate, int avoid = 0) {
     DenseBlock d{-1, -1, 0, first_gate};
     int pos_up = L::on_lane(up) ? -1 : L::reg_bit(up), pos_dn = L::on_lane(dn) ? -1 : L::reg_bit(dn);
+    int lanes = 0, freeq = 0;
+    for (int q = 0; q < L::NQ; q++) {
+        if (L::on_lane(q)) { if (q == up || q == dn) lanes++; }
+        else if (q != up && q != dn && !((avoid >> q) & 1)) freeq++;
+    }
+    if (freeq < lanes) avoid = 0;                             // not enough register qubits left: plain rule
     int next_q = 0, nswap = 0;
     for (int which = 0; which < 2; which++) {
         const int q = which == 0 ? up : dn;
         if (!L::on_lane(q)) continue;
-        while (next_q == up || next_q == dn || L::on_lane(next_q)) next_q++;       // a register qubit outside the pair
+        while (next_q == up || next_q == dn || L::on_lane(next_q) || ((avoid >> next_q) & 1)) next_q++;       // a register qubit outside the pair
         const int rb = L::reg_bit(next_q++);
         if (nswap == 0) d.x = (L::lane_bit(q) << 8) | rb; else d.y = (L::lane_bit(q) << 8) | rb;
         nswap++;
@@ -96,6 +103,32 @@ __host__ __device__ constexpr DenseBlock dense_block_entry(int up, int dn, int f
     const int ra = pos_up < pos_dn ? pos_up : pos_dn, rb = pos_up < pos_dn ? pos_dn : pos_up;
     d.z = ra | (rb << 4) | (pos_up == ra ? 256 : 0);
     return d;
+}
+
+// Block at position J of a layer of LL pairs ud[]: when the previous / next block of the (cyclic) layer shares a lane qubit
+// with it, neither exchanges that qubit with a register qubit of the other's pair - both then choose the SAME register
+// qubit, and the sweeps of a layer-specialised kernel keep the qubit in registers across the two blocks instead of
+// exchanging it back and forth (dense_same_swap).  The host's table uses the same rule (same pair positions).
+template <class L>
+__host__ __device__ constexpr DenseBlock dense_layer_entry(const int* ud, int LL, int J, int first_gate) {
+    const int up = ud[2 * J], dn = ud[2 * J + 1];
+    int avoid = 0;
+    if (LL > 1) {
+        const int nb[2] = {(J + LL - 1) % LL, (J + 1) % LL};
+        for (int k = 0; k < 2; k++) {
+            const int u2 = ud[2 * nb[k]], d2 = ud[2 * nb[k] + 1];
+            const bool shares = (L::on_lane(up) && (up == u2 || up == d2)) || (L::on_lane(dn) && (dn == u2 || dn == d2));
+            if (shares) avoid |= (1 << u2) | (1 << d2);
+        }
+    }
+    return dense_block_entry<L>(up, dn, first_gate, avoid);
+}
+// blocks at layer positions J1, J2 make the same single exchange: it can stay in place from one to the other
+template <class L>
+__host__ __device__ constexpr bool dense_same_swap(const int* ud, int LL, int J1, int J2) {
+    if (J1 < 0 || J2 < 0 || J1 >= LL || J2 >= LL) return false;
+    const DenseBlock a = dense_layer_entry<L>(ud, LL, J1, 0), b = dense_layer_entry<L>(ud, LL, J2, 0);
+    return a.x >= 0 && a.x == b.x && a.y < 0 && b.y < 0;
 }
 
 // ---- packed complex helpers --------------------------------------------------------------------------------------
@@ -524,15 +557,19 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             int b = 0;
             auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
                 constexpr int J = decltype(jj)::value;
-                constexpr DenseBlock ent = dense_block_entry<L>(PL::v[2 * J], PL::v[2 * J + 1], 0);
+                constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
                 constexpr int RA = ent.z & 15, RB = (ent.z >> 4) & 15;
+                // the exchange stays in place between two blocks of the layer that make the same one (not across the layer's end)
+                constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J - 1, J), KEEP = dense_same_swap<L>(PL::v, LL, J, J + 1);
                 f2 g[16];
                 load_block_matrix(smem + lds.gm + 32 * b, g);
-                if constexpr (ent.x >= 0) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                if constexpr (ent.x >= 0 && !KEPT) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
                 if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
                 dense_apply<E, RA, RB, false>(psi, g);
                 if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
-                if constexpr (ent.x >= 0) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                if constexpr (ent.x >= 0) {
+                    if (!KEEP || b + 1 >= K) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);       // the last block of the circuit always exchanges back
+                }
                 b++;
             };
             for (int full = K / LL; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
@@ -635,14 +672,19 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             int b = K - 1;
             auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
                 constexpr int J = LL - 1 - decltype(jj)::value;
-                constexpr DenseBlock ent = dense_block_entry<L>(PL::v[2 * J], PL::v[2 * J + 1], 0);
+                constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
+                // mirror image of the forward sweep: block J + 1 (swept just before) leaves the exchange in place unless it
+                // was the last block of the circuit's own (b + 1 == K: nothing was swept before this block)
+                constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J, J + 1), KEEP = dense_same_swap<L>(PL::v, LL, J - 1, J);
                 f2 g[16];
                 load_block_matrix(smem + lds.gm + 32 * b, g);
-                if constexpr (ent.x >= 0) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                if constexpr (ent.x >= 0) {
+                    if (!KEPT || b + 1 >= K) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                }
                 if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
                 bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, g, b);
                 if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
-                if constexpr (ent.x >= 0) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                if constexpr (ent.x >= 0 && !KEEP) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
                 b--;
             };
             const int tail = K % LL;                         // blocks beyond the last whole layer come first

@@ -314,7 +314,9 @@ int dense_table(cpf_plan* plan, DevBuf& tab) {
     if (tab.p) return 0;
     const int K = plan->K, per_block = 1 + 2 * plan->n_rot;
     std::vector<cpf::DenseBlock> h((size_t)K);
-    for (int b = 0; b < K; b++) h[b] = cpf::dense_block_entry<L>(plan->h_place[2 * b], plan->h_place[2 * b + 1], 3 * plan->n + per_block * b);
+    // the same layer-aware rule as the layer-specialised kernels (cpf_dense.h dense_layer_entry): pair positions must agree
+    const int LLn = (int)plan->layer_ud.size() / 2;
+    for (int b = 0; b < K; b++) h[b] = cpf::dense_layer_entry<L>(plan->layer_ud.data(), LLn, b % LLn, 3 * plan->n + per_block * b);
     CPF_HIP(tab.alloc(h.size() * sizeof(cpf::DenseBlock)));
     CPF_HIP(hipMemcpy(tab.p, h.data(), h.size() * sizeof(cpf::DenseBlock), hipMemcpyHostToDevice));
     return 0;
