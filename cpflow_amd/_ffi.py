@@ -54,6 +54,7 @@ SYMBOLS = {
     'cpf_plan_last_kernel_ms': (_I32, [_VP, C.POINTER(C.c_float)]),
     'cpf_plan_last_variant': (_I32, [_VP, C.c_char_p, C.c_size_t]),
     'cpf_jit_compiles': (_I32, []),
+    'cpf_set_tuning': (_I32, [C.c_char_p, C.c_char_p]),
     'cpf_jit_precompile': (_I32, [C.POINTER(Problem), _I64, C.c_char_p, C.c_size_t]),
     'cpf_run_static': (_I32, [C.POINTER(Problem), _I32, _U32, _I64, _I64, _I64, _I32, _VP, _VP, C.POINTER(Result)]),
 }
@@ -88,3 +89,8 @@ def check(rc):
         if rc < 0:
             raise ValueError(f'cpflow_amd: {msg} (code {rc})')
         raise CpfError(f'cpflow_amd: {msg} (hip error {rc})')
+
+
+def set_tuning(name, value=None):
+    """Kernel-selection switch of the library (tests, A/B tools): value None restores the default."""
+    check(lib().cpf_set_tuning(name.encode(), None if value is None else str(value).encode()))

@@ -105,11 +105,13 @@ def precompile(shapes=None, workers=None, verbose=True):
     return sorted(seen)
 
 
-def _precompile_one(layer, rot, K, S, entangler='cp'):
+def _precompile_one(layer, rot, K, S, entangler='cp', tuning=None):
     import ctypes as C
     import numpy as np
     from . import _ffi
     from .engine import placements_for, problem_struct
+    for name, value in (tuning or {}).items():
+        _ffi.set_tuning(name, value)
     n = max(max(p) for p in layer) + 1
     pl, target, rotb = placements_for(layer, K), np.ascontiguousarray(np.eye(1 << n, dtype=np.complex128)), rot.encode()
     pb = problem_struct(n, pl, rotb, entangler, 'hst', target)

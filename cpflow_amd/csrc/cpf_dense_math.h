@@ -13,7 +13,7 @@
 //                     (the same formula the gate-by-gate kernels evaluate on the full state, cpf_device.h rot_grad).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CPF_HD __host__ __device__ __forceinline__
 #else
 #define CPF_HD inline

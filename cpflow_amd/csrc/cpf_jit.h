@@ -9,6 +9,7 @@
 //   2. $CPF_JIT_CACHE or ~/.cache/cpflow_amd   (per user, mode 0700)
 //   3. a compile: hipcc --genco as a child process (posix_spawn, no shell; profiler preloads stripped from its
 //      environment), hiprtc in-process as the fallback and whenever a profiler is attached to this process.
+// A cached hiprtc object is only accepted by a process that would itself build with hiprtc (or may not compile).
 // CPF_JIT_FORBID_COMPILE=1 turns step 3 into an error (a test can prove that a box never compiles), CPF_JIT=0 disables
 // the whole path.  Failures are remembered per kernel, so a launch loop does not re-run a failing compiler.
 #pragma once
@@ -69,10 +70,12 @@ inline bool private_dir(const std::string& d) {
            access(d.c_str(), W_OK) == 0;
 }
 inline std::string shipped_dir() { return lib_dir() + "/jit_cache"; }
-inline std::string cache_dir() {
+// note (optional): set when an explicit $CPF_JIT_CACHE was rejected and another directory is used instead
+inline std::string cache_dir(std::string* note = nullptr) {
     const char* e = getenv("CPF_JIT_CACHE");
     const std::string first = e ? std::string(e) : std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/cpflow_amd";
     if (private_dir(first)) return first;
+    if (e && note) *note = " [CPF_JIT_CACHE=" + first + " rejected: it must be a directory owned by this user, writable, and not group/world-writable]";
     const std::string fallback = "/tmp/cpflow_amd_cache_" + std::to_string((long)getuid());      // read-only home
     if (private_dir(fallback)) return fallback;
     char tmpl[] = "/tmp/cpflow_amd_XXXXXX";                                                       // someone else owns that name
@@ -128,7 +131,7 @@ struct Spec {
     std::vector<std::string> flags;          // extra compiler flags (e.g. -mllvm options)
 };
 
-struct Code { std::string bytes, backend, error; bool compiled = false; };    // backend: "hipcc" | "hiprtc"
+struct Code { std::string bytes, backend, error, note, path; bool compiled = false; };    // note: why $CPF_JIT_CACHE was not used; path: where a compiled object was written    // backend: "hipcc" | "hiprtc"
 
 inline std::atomic<int>& compile_counter() { static std::atomic<int> n{0}; return n; }
 
@@ -158,20 +161,27 @@ inline Code build(const Spec& sp) {
         snprintf(hname, sizeof(hname), "%016llx", (unsigned long long)fnv1a(salt, fnv1a(hdrs)));
         return std::string(hname) + ".hsaco";
     };
-    // an object built by hipcc is the preferred one wherever it is found, whatever could be built here and now
+    const char* forbid_env = getenv("CPF_JIT_FORBID_COMPILE");
+    const bool forbid = forbid_env && forbid_env[0] == '1';
+    const bool use_hipcc = be ? std::string(be) == "hipcc" : (have_hipcc && !profiler_attached());
+    // An object built by hipcc is the preferred one wherever it is found.  A cached hiprtc object (2x slower code, above)
+    // is accepted only where this process would not build with hipcc anyway - no hipcc installed, a profiler attached,
+    // CPF_JIT_BACKEND=hiprtc, or compiling forbidden - so that one profiled run cannot pin the slow object for every
+    // later run of the shape: those fall through to the hipcc compile.
+    std::string dir_note;
+    const std::string cdir = cache_dir(&dir_note);
     for (const char* backend : {"hipcc", "hiprtc"}) {
         if (be && std::string(be) != backend) continue;
-        for (const std::string& dir : {shipped_dir(), cache_dir()}) {
+        if (!strcmp(backend, "hiprtc") && use_hipcc && !forbid) continue;
+        for (const std::string& dir : {shipped_dir(), cdir}) {
             if (dir.empty()) continue;
             out.bytes = read_file(dir + "/" + name_for(backend));
             if (!out.bytes.empty()) { out.backend = backend; return out; }
         }
     }
-    { const char* f = getenv("CPF_JIT_FORBID_COMPILE");
-      if (f && f[0] == '1') { out.error = "run-time compile forbidden (CPF_JIT_FORBID_COMPILE=1) and no cached object for " + sp.body; return out; } }
-    const bool use_hipcc = be ? std::string(be) == "hipcc" : (have_hipcc && !profiler_attached());
-    const std::string cdir = cache_dir();
-    if (cdir.empty()) { out.error = "no writable private cache directory"; return out; }
+    if (forbid) { out.error = "run-time compile forbidden (CPF_JIT_FORBID_COMPILE=1) and no cached object for " + sp.body + dir_note; return out; }
+    if (cdir.empty()) { out.error = "no writable private cache directory" + dir_note; return out; }
+    out.note = dir_note;
     // ranks of one job may build the same kernel at the same time: private temporaries, atomic rename
     if (use_hipcc) {
         const std::string cpath = cdir + "/" + name_for("hipcc"), tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
@@ -187,7 +197,7 @@ inline Code build(const Spec& sp) {
             out.bytes = read_file(tmp);
             rename(tmp.c_str(), cpath.c_str());
             unlink((tmp + ".log").c_str());
-            if (!out.bytes.empty()) { out.backend = "hipcc"; out.compiled = true; compile_counter()++; return out; }
+            if (!out.bytes.empty()) { out.backend = "hipcc"; out.compiled = true; out.path = cpath; compile_counter()++; return out; }
         }
         out.error = "hipcc --genco failed (exit " + std::to_string(rc) + "), see " + tmp + ".log; ";
         if (be) return out;
@@ -214,7 +224,7 @@ inline Code build(const Spec& sp) {
     const std::string cpath = cdir + "/" + name_for("hiprtc"), tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
     { std::ofstream o(tmp, std::ios::binary); o << out.bytes; }
     rename(tmp.c_str(), cpath.c_str());
-    out.backend = "hiprtc"; out.compiled = true; out.error.clear(); compile_counter()++;
+    out.backend = "hiprtc"; out.compiled = true; out.path = cpath; out.error.clear(); compile_counter()++;
     return out;
 }
 

@@ -26,6 +26,21 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Kernel-selection switches (two-ended vs one-wave, stored states, dense blocks, relabelling ...) are set through
+// cpf_set_tuning (include/cpflow_amd.h) by the tests and the A/B tools.  The release library reads no CPF_* environment
+// variable for them; a build with -DCPF_ENV_TUNING falls back to the environment (tools/).
+std::map<std::string, std::string>& tuning_map() { static std::map<std::string, std::string> m; return m; }
+const char* tuning(const char* name) {
+    auto& m = tuning_map();
+    auto it = m.find(name);
+    if (it != m.end()) return it->second.c_str();
+#ifdef CPF_ENV_TUNING
+    return getenv(name);
+#else
+    return nullptr;
+#endif
+}
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -160,7 +175,7 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
 // resident workgroups the launch needs (S / CUs, at most ~5 per SIMD by registers).
 bool phases_fit(const cpf_plan* plan, int64_t S, size_t lds_bytes_with_phases) {
     const int num_cu = plan->num_cu;
-    { const char* e = getenv("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    { const char* e = tuning("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // same-box A/B (ms, store vs rebuild): config 2 S=1024 10.06/10.53, S=4096 24.45/26.15, S=16384 96.1/93.5;
     // config 3 S=1024 12.89/13.75, S=4096 38.5/35.4 -> store only while LDS still admits the workgroups the launch
     // wants per CU (registers cap that at ~20)
@@ -173,16 +188,16 @@ bool phases_fit(const cpf_plan* plan, int64_t S, size_t lds_bytes_with_phases) {
 // (config 2 shape, same box: S = 2048 15.1 vs 17.8 ms, 16384 84.2 vs 93.7 ms; config 3 shape S = 4096 28.8 vs 33.8 ms).
 bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int rot_code, int64_t S, bool kspec) {
     if (!cpf::layered_merge(3, 0, rot_code) || !cpf::split_supported(K, LL) || a.loss_kind == 2) return false;
-    { const char* e = getenv("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
+    { const char* e = tuning("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
     return kspec || S <= (int64_t)plan->num_cu * 4;
 }
-bool kspec_enabled() { const char* e = getenv("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
+bool kspec_enabled() { const char* e = tuning("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
 // Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
 // them while LDS still admits the workgroups the launch wants on a CU.
 bool states_fit(const cpf_plan* plan, int64_t S, int rot_code, size_t lds_bytes_with_states) {
     const int num_cu = plan->num_cu;
     if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > 64 * 1024) return false;
-    { const char* e = getenv("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    { const char* e = tuning("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // only while every workgroup of the launch is resident at once (same box, config 2 shape: S = 1024 6.95 vs 7.15 ms
     // with / without states, S = 2048 17.5 vs 15.1, S = 4096 32.1 vs 22.8)
     return (int64_t)(plan->lds_per_cu / (int64_t)lds_bytes_with_states) >= (S + num_cu - 1) / num_cu;
@@ -201,7 +216,7 @@ int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStre
         // samples), 5.63 -> 4.83 (256).  With four samples per CU neither helps (6.03 -> 6.35 ms at config 2).
         const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
         int pairs = per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0);
-        { const char* e = getenv("CPF_PAIRS"); if (e) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
+        { const char* e = tuning("CPF_PAIRS"); if (e) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
         if (pairs == 2 && (S < 2 || ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * lds2) > plan->lds_per_cu)) pairs = 0;
         if (pairs == 1 && !states_fit(plan, S, ROT, lds2)) pairs = 0;
         if (pairs == 2) {
@@ -263,7 +278,7 @@ bool launch_layered3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S,
     return false;
 }
 bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    { const char* e = getenv("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
+    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
         plan->entangler != CPF_ENTANGLER_CP || plan->K < 1)
         return false;
@@ -289,7 +304,7 @@ int launch_layered_aot(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream
     return 0;
 }
 bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
-    { const char* e = getenv("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
+    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP ||
         plan->rot != "xyz")
         return false;
@@ -338,11 +353,11 @@ cpf_jit::Spec dense_jit_spec(int nq, int lw, const std::vector<int>& ud) {
 }
 bool dense_wanted(const cpf_plan* plan, int mode) {
     if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
-    const char* e = getenv("CPF_DENSE");
+    const char* e = tuning("CPF_DENSE");
     return e ? e[0] != '0' : plan->NQ == 6;
 }
 int dense_lw(const cpf_plan* plan, int64_t S) {
-    const char* w = getenv("CPF_DENSE_LW");
+    const char* w = tuning("CPF_DENSE_LW");
     const int64_t simds = (int64_t)plan->num_cu * 4;
     switch (plan->NQ) {
         case 6: return (w && w[0] == '2') ? 2 : 1;
@@ -351,7 +366,7 @@ int dense_lw(const cpf_plan* plan, int64_t S) {
     }
 }
 bool dense_specialised(const cpf_plan* plan) {
-    const char* sp = getenv("CPF_DENSE_SPECIALISED");               // A/B and tests: 0 = table-dispatched instance only
+    const char* sp = tuning("CPF_DENSE_SPECIALISED");               // A/B and tests: 0 = table-dispatched instance only
     return !(sp && sp[0] == '0') && !plan->layer_ud.empty() && plan->layer_ud.size() <= 32;
 }
 
@@ -377,11 +392,13 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     const std::string waves = " waves=" + std::to_string(wps);
     if (specialised) {
         const bool have_aot = dense_has_aot(nq, lw, plan->layer_ud);
-        if (!have_aot && plan->use_jit) {
+        // a module kernel cannot opt in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute takes a registered host
+        // symbol): such shapes (K >~ 100 at 6 qubits) take the ahead-of-time table kernel below
+        if (!have_aot && plan->use_jit && lds > 64 * 1024) plan->jit_note = "LDS footprint above 64 KiB";
+        if (!have_aot && plan->use_jit && lds <= 64 * 1024) {
             const cpf_jit::Spec spec = dense_jit_spec(nq, lw, plan->layer_ud);
             const cpf_jit::Kernel& k = cpf_jit::get(plan->device, spec);
             if (k.fn) {
-                if (lds > 64 * 1024) CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 cpf::DenseArgs args = da;
                 void* params[] = {&args};
                 e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
@@ -432,7 +449,7 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
     const int rot_code = cpf::rot_with_ent(cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]), plan->entangler == CPF_ENTANGLER_CZ ? 1 : (plan->entangler == CPF_ENTANGLER_CX ? 2 : 0));
     cpf::KArgs a{};
     a.loss_kind = loss_kind;
-    const char* jk = getenv("CPF_JIT_K");                                        // opt-in: one build per block count
+    const char* jk = tuning("CPF_JIT_K");                                        // opt-in: one build per block count
     const bool jit_k = jk && jk[0] == '1';
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = ppt_bucket((P + 127) / 128);
@@ -474,6 +491,15 @@ std::string tag_with_backend(const std::string& tag, const std::string& backend)
     return t;
 }
 
+// cpf_jit_precompile: an object that was built must have been written under $CPF_JIT_CACHE when that is set (a rejected
+// directory would otherwise leave the shipped cache empty while the build reports success)
+int precompile_landed(const cpf_jit::Code& code, const std::string& body) {
+    const char* want = getenv("CPF_JIT_CACHE");
+    if (!code.compiled || !want) return 0;
+    if (code.path.rfind(std::string(want) + "/", 0) == 0) return 0;
+    return fail(-32, "precompile of %s: object written to %s, not under CPF_JIT_CACHE=%s%s", body.c_str(), code.path.c_str(), want, code.note.c_str());
+}
+
 // lw = log2(waves per sample).  Returns true when a specialised kernel was launched (or a hard error is in *rc).
 bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE) return false;
@@ -505,7 +531,7 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
         case 6: lw = 2; break;
         default: lw = 0;
     }
-    { const char* e = getenv("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
+    { const char* e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
     return lw;
 }
@@ -521,7 +547,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     cpf::KArgs a = a_in;
     a.nsamples = (int)S;
     a.lone = S <= plan->num_cu ? 1 : 0;
-    { const char* e = getenv("CPF_LONE"); if (e) a.lone = e[0] == '1'; }      // A/B and tests
+    { const char* e = tuning("CPF_LONE"); if (e) a.lone = e[0] == '1'; }      // A/B and tests
     {
         const int which = labelling_for(plan, a.mode, lw);
         select_labelling(plan, which);
@@ -551,8 +577,8 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     pl->P = 3 * pl->n + pl->nb * pl->K;
     pl->T = pb->num_iterations;
     pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
-    { const char* fg = getenv("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
-    { const char* fj = getenv("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
+    { const char* fg = tuning("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
+    { const char* fj = tuning("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
     // Qubit relabelling (4 and 5 qubits, gate-by-gate kernel, one wave per sample).  That layout keeps the kernel's LAST
     // row qubits in registers (cpf_device.h Lay: a rotation there is 2 packed instructions per amplitude, on a lane qubit 3,
@@ -563,8 +589,8 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     // sample every row qubit sits on lanes and the problem's own labels are kept (the 4-qubit star at 500 samples: 25.2 ms
     // against 28.6 relabelled), hence the choice per launch.
     pl->has_relabel = (pl->NQ == 4 || pl->NQ == 5) && pl->n == pl->NQ;
-    { const char* e = getenv("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
-    { const char* e = getenv("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
+    { const char* e = tuning("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
+    { const char* e = tuning("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
     for (int which = 0; which < 2; which++) {
         cpf_plan::Labelling& lb = pl->lab[which];
         lb.qperm.resize((size_t)pl->n);
@@ -603,6 +629,19 @@ int32_t cpf_device_count(void) {
 }
 
 const char* cpf_last_error(void) { return g_err; }
+
+int32_t cpf_set_tuning(const char* name, const char* value) {
+    static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW",
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_MFMA", "CPF_RELABEL", "CPF_FORCE_GENERIC",
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
+    if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
+    for (const char* k : known)
+        if (!strcmp(k, name)) {
+            if (value) tuning_map()[name] = value; else tuning_map().erase(name);
+            return 0;
+        }
+    return fail(-1, "cpf_set_tuning: unknown switch '%s'", name);
+}
 
 int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_plan) {
     if (!out_plan) return fail(-1, "out_plan is NULL");
@@ -779,7 +818,7 @@ int32_t cpf_optimize_device(const cpf_plan* plan_c, int64_t S, const float* d_in
     CPF_HIP(hipSetDevice(plan->device));
     cpf::KArgs a = plan->base;
     a.mode = cpf::MODE_OPTIMIZE;
-    { const char* e = getenv("CPF_PRIO"); a.prio = e ? (e[0] == '1') : (S <= (int64_t)plan->num_cu * 8); }   // A/B: CPF_PRIO=0|1
+    { const char* e = tuning("CPF_PRIO"); a.prio = e ? (e[0] == '1') : (S <= (int64_t)plan->num_cu * 8); }   // A/B: CPF_PRIO=0|1
     a.init = d_init; a.frozen = d_frozen;
     a.out_params = d_params; a.out_regloss = d_regloss; a.out_loss = d_loss; a.out_reg = d_reg;
     a.out_cz = d_cz; a.out_pass = d_pass;
@@ -856,6 +895,7 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
             const cpf_jit::Spec spec = dense_jit_spec(pl.NQ, lw, pl.layer_ud);
             const cpf_jit::Code code = cpf_jit::build(spec);
             if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
+            if (int rc = precompile_landed(code, spec.body)) return rc;
             report = "dense/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
             built = 1;
         }
@@ -867,6 +907,7 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {
         const cpf_jit::Code code = cpf_jit::build(c.spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", c.spec.body.c_str(), code.error.c_str());
+        if (int rc = precompile_landed(code, c.spec.body)) return rc;
         report += tag_with_backend(c.tag, code.backend) + (code.compiled ? " [built] " : " [cached] ") + c.spec.body + "\n";
         built++;
     }

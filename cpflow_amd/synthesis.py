@@ -149,11 +149,10 @@ class Decomposition:
 
     def refine(self, max_denominator=32, angle_threshold=0.01, cp_threshold=0.01, reduce_threshold=1e-5,
                recursion_degree=0, recursion_depth=5):
-        """Angle reduction and rationalisation of the 1q gates (cpflow_amd.refine); the
-        Clifford+T step of the reference needs qiskit's Solovay-Kitaev pass and is not provided."""
-        from .refine import refine_decomposition
-        return refine_decomposition(self, max_denominator=max_denominator, angle_threshold=angle_threshold,
-                                    cp_threshold=cp_threshold, reduce_threshold=reduce_threshold)
+        """Signature of cpflow's Decomposition.refine (main.py:283-317).  Refinement (angle rationalisation, Solovay-Kitaev)
+        is qiskit-bound CPU post-processing that stays in cpflow (exact_decompositions.py; SURVEY 2a: out of scope here)."""
+        raise NotImplementedError('refine is CPU post-processing that stays in cpflow (cpflow/exact_decompositions.py); '
+                                  'hand decomposition.circuit.data (gate list) to it')
 
     def __repr__(self):
         text = (f"< {self.label}| {self.type} | loss: {self.loss}  | CZ count: {self.cz_count} "

@@ -29,3 +29,29 @@ def _native_libraries():
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+class _Tuning:
+    """Kernel-selection switches of the library (cpf_set_tuning, include/cpflow_amd.h), restored after the test."""
+    def __init__(self):
+        self._names = set()
+
+    def set(self, name, value):
+        from cpflow_amd import _ffi
+        _ffi.set_tuning(name, value)
+        self._names.add(name)
+
+    def unset(self, name):
+        from cpflow_amd import _ffi
+        _ffi.set_tuning(name, None)
+
+    def clear(self):
+        for n in self._names:
+            self.unset(n)
+
+
+@pytest.fixture
+def tune():
+    t = _Tuning()
+    yield t
+    t.clear()

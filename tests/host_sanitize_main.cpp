@@ -50,6 +50,28 @@ int main(int argc, char** argv) {
     n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));
     CHECK(n == 2 && strstr(buf, "[cached]") && !strstr(buf, "[built]"));
     CHECK(cpf_jit_compiles() == 2);
+    // a cached hiprtc object (2x slower code) must not pin itself: built under CPF_JIT_BACKEND=hiprtc (as a profiled run
+    // would), it is reused by a process that asks for hiprtc again, but a normal process with hipcc installed builds
+    // the hipcc object instead of accepting it; and an unknown tuning switch is rejected
+    {
+        std::vector<int32_t> chain3b; for (int b = 0; b < 7; b++) { chain3b.push_back(b % 2 ? 2 : 1); chain3b.push_back(b % 2 ? 1 : 0); }
+        cpf_problem pr = problem(3, chain3b, "xy", t3);
+        setenv("CPF_JIT_BACKEND", "hiprtc", 1);
+        n = cpf_jit_precompile(&pr, 64, buf, sizeof(buf));
+        CHECK(n >= 1 && strstr(buf, "(hiprtc)") && strstr(buf, "[built]"));
+        n = cpf_jit_precompile(&pr, 64, buf, sizeof(buf));
+        CHECK(n >= 1 && strstr(buf, "(hiprtc)") && strstr(buf, "[cached]") && !strstr(buf, "[built]"));
+        unsetenv("CPF_JIT_BACKEND");
+        n = cpf_jit_precompile(&pr, 64, buf, sizeof(buf));
+        CHECK(n >= 1 && strstr(buf, "(hipcc)") && strstr(buf, "[built]") && !strstr(buf, "(hiprtc)"));
+        setenv("CPF_JIT_FORBID_COMPILE", "1", 1);               // may not compile: whatever the cache holds is taken, hipcc first
+        n = cpf_jit_precompile(&pr, 64, buf, sizeof(buf));
+        CHECK(n >= 1 && strstr(buf, "(hipcc)") && strstr(buf, "[cached]"));
+        unsetenv("CPF_JIT_FORBID_COMPILE");
+        CHECK(cpf_set_tuning("CPF_NOT_A_SWITCH", "1") < 0 && cpf_set_tuning("CPF_SPLIT", "0") == 0 && cpf_set_tuning("CPF_SPLIT", nullptr) == 0);
+    }
+    const int compiles_so_far = cpf_jit_compiles();
+    CHECK(compiles_so_far >= 4);
     // shapes served by ahead-of-time kernels need nothing: config 2 (3 qubits, chain) -> the JIT candidates exist but are never
     // reached at run time; config 5 (6 qubits on a ring) -> the dense-block instance is built ahead of time
     std::vector<int32_t> ring6; for (int b = 0; b < 60; b++) { ring6.push_back(b % 6); ring6.push_back((b % 6 + 1) % 6); }

@@ -133,7 +133,7 @@ def test_short_adam_trajectory_matches_fp32_oracle(layer, K, rot):
     ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', '2'), ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', '0'),
     ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', '2'), ([[0, 5], [2, 3], [4, 1]], 5, 'zx', '2'),
 ])
-def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw, monkeypatch):
+def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw, monkeypatch, tune):
     """The hiprtc-specialised layered kernel (cpf_layered.h), the ahead-of-time generic kernel and the
     float64 oracle agree on short Adam runs (incl. frozen angles); 1 and 4 waves per sample."""
     n = max(max(p) for p in layer) + 1
@@ -143,12 +143,12 @@ def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw
     init = orc.initial_angles(3, S)
     frozen = np.zeros((S, orc.P), dtype=np.uint8)
     frozen[1::2, ::5] = 1
-    monkeypatch.setenv('CPF_LW', lw)
-    monkeypatch.setenv('CPF_SPLIT', '0')          # the two-ended 3-qubit kernel has its own test below
-    monkeypatch.setenv('CPF_DENSE', '0')          # ... and so has the dense-block kernel
+    tune.set('CPF_LW', lw)
+    tune.set('CPF_SPLIT', '0')          # the two-ended 3-qubit kernel has its own test below
+    tune.set('CPF_DENSE', '0')          # ... and so has the dense-block kernel
     outs = {}
     for jit in ('1', '0'):
-        monkeypatch.setenv('CPF_JIT', jit)
+        tune.set('CPF_JIT', jit)
         eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
         outs[jit] = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
         outs[jit + 'f'] = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
@@ -335,7 +335,7 @@ def test_two_qubit_problems_run_on_the_three_qubit_kernels(ent, layer, K, rot, S
 
 @pytest.mark.parametrize('layer,K,rot', [([[0, 1], [0, 2], [0, 3]], 7, 'xyz'), ([[0, 1], [1, 2], [2, 3], [3, 4]], 9, 'xz'),
                                          ([[2, 1], [1, 3], [1, 0]], 6, 'zy')])
-def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch):
+def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch, tune):
     """With one wave per sample the 4- and 5-qubit kernels keep their last row qubits in registers, so the library relabels
     the problem's qubits (most-used last; placements, gate program, target rows and columns) for those launches.
     Parameters, the unitary entry point and every result stay in the problem's own labels: same history as the float64
@@ -348,7 +348,7 @@ def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch)
     ref = orc.run(theta[:6], np.float64, keep_history=True)
     res = {}
     for relabel in ('1', '0'):
-        monkeypatch.setenv('CPF_RELABEL', relabel)
+        tune.set('CPF_RELABEL', relabel)
         eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
         out = {k: v.cpu().numpy() for k, v in eng.optimize(theta, keep_history=True).items()}
         assert eng.last_variant().startswith('layered/jit') and eng.last_variant().endswith('waves=1'), eng.last_variant()
@@ -367,7 +367,7 @@ def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch)
     assert (res['0']['params'][:, 0] == res['1']['params'][:, 0]).all()
 
 
-def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch):
+def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch, tune):
     """CPF_JIT_K=1 (one build per block count) with a 2-qubit problem: the parameter count the kernel derives from its
     compile-time K must use the problem's two qubits, not the kernel's three (found by tools/gpu.py fuzz)."""
     layer, K, rot = [[0, 1]], 7, 'xyz'
@@ -375,7 +375,7 @@ def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch):
     orc = Oracle(layer, K, target, rot, entangler='cz', num_gd_iterations=8)
     theta = np.random.default_rng(1).uniform(0, 2 * np.pi, size=(3, orc.P)).astype(np.float32)
     ref = orc.run(theta, np.float64, keep_history=True)
-    monkeypatch.setenv('CPF_JIT_K', '1')
+    tune.set('CPF_JIT_K', '1')
     eng = _engine(layer, K, target, rot, entangler='cz', num_gd_iterations=8, use_reg=False)
     out = eng.optimize(theta, keep_history=True)
     assert eng.last_variant().startswith('split/jit') and eng.last_variant().endswith(' K'), eng.last_variant()
@@ -386,15 +386,15 @@ def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch):
 @pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 12, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 16, 'xyz'),
                                          ([[0, 1], [1, 2]], 7, 'xz'), ([[2, 0], [1, 2], [0, 1]], 5, 'xyz'),
                                          ([[0, 1], [0, 2], [1, 2]], 1, 'xz'), ([[1, 0], [2, 0]], 4, 'yz')])
-def test_merged_diagonal_runs_both_variants(layer, K, rot, mstore, monkeypatch):
+def test_merged_diagonal_runs_both_variants(layer, K, rot, mstore, monkeypatch, tune):
     """3-qubit kernels merge each run Rz(up) Rz(dn) CP(next) into one phase; the phase is either kept in LDS
     for the backward pass (CPF_MSTORE=1) or rebuilt there (0).  Both against the float64 oracle, including
     truncated layers, twisted pairs, a single block and a 2-letter rotation string."""
     n = 3
     target = _rand_unitary(n, 21)
     T, S = 14, 5
-    monkeypatch.setenv('CPF_MSTORE', mstore)
-    monkeypatch.setenv('CPF_SPLIT', '0')
+    tune.set('CPF_MSTORE', mstore)
+    tune.set('CPF_SPLIT', '0')
     orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     init = orc.initial_angles(9, S)
@@ -412,7 +412,7 @@ def test_merged_diagonal_runs_both_variants(layer, K, rot, mstore, monkeypatch):
                                          ([[0, 1], [1, 2]], 4, 'z'), ([[1, 0], [2, 0]], 5, 'yz'),
                                          ([[1, 2], [0, 1]], 5, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 64, 'xz')])
 @pytest.mark.parametrize('pstore,kspec', [('0', '0'), ('1', '1'), ('1', '0'), ('0', '1')])
-def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypatch):
+def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypatch, tune):
     """Two waves per sample (cpf_split.h): wave A builds the first half of the circuit from the identity, wave B
     un-applies the second half from the target, gradients come from a backward sweep (A) and a forward sweep (B).
     Against the float64 oracle over a short run with history, a frozen mask and the penalty on; ahead-of-time and
@@ -420,10 +420,10 @@ def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypat
     psi and C (pstore 0) or read stored states back (pstore 1), K from the plan or as a compile-time constant."""
     target = _rand_unitary(3, 22)
     T, S = 14, 5
-    monkeypatch.setenv('CPF_SPLIT', '1')
-    monkeypatch.setenv('CPF_PSTORE', pstore)
-    monkeypatch.setenv('CPF_KSPEC', kspec)
-    monkeypatch.setenv('CPF_JIT_K', kspec)
+    tune.set('CPF_SPLIT', '1')
+    tune.set('CPF_PSTORE', pstore)
+    tune.set('CPF_KSPEC', kspec)
+    tune.set('CPF_JIT_K', kspec)
     orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     init = orc.initial_angles(9, S)
@@ -459,7 +459,7 @@ def test_two_ended_kernel_matches_oracle(layer, K, rot, pstore, kspec, monkeypat
 @pytest.mark.parametrize('layer,K', [([[0, 1], [1, 2]], 12), ([[0, 1], [0, 2], [1, 2]], 16)])
 @pytest.mark.parametrize('pairs,S,variant', [('2', 7, 'split/aot waves=2 states K pairs=2'), ('2', 2, 'split/aot waves=2 states K pairs=2'),
                                              ('1', 5, 'split/aot waves=2 states K lone'), ('0', 6, 'split/aot waves=2 states K')])
-def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, monkeypatch):
+def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, monkeypatch, tune):
     """The K-specialised stored-state kernel comes in three forms: the cut measured best with two waves per SIMD; the cut
     that balances the two waves' chains for launches with one wave per SIMD ('lone'); and that cut with TWO samples per
     workgroup (four waves), which the launch uses at two samples per CU because two-wave workgroups are placed one SIMD
@@ -467,7 +467,7 @@ def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, m
     last workgroup's second pair runs a masked copy)."""
     target = _rand_unitary(3, 41)
     T = 14
-    monkeypatch.setenv('CPF_PAIRS', pairs)
+    tune.set('CPF_PAIRS', pairs)
     orc = Oracle(layer, K, target, 'xyz', num_gd_iterations=T, r=0.004)
     eng = _engine(layer, K, target, 'xyz', num_gd_iterations=T, r=0.004)
     init = orc.initial_angles(3, S)
@@ -490,7 +490,7 @@ def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, m
     assert (hp[:, -1, 2::3] != init[:, 2::3]).any()
 
 
-def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
+def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch, tune):
     """Same inputs through both 3-qubit kernels: identical first losses up to rounding, the same CZ counts on a
     short run, the same end-of-run statistics on config 2's shape; the relative-phase loss (non-linear
     cotangent) and K > 64 stay on the one-wave kernel."""
@@ -498,7 +498,7 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
     ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
     res = {}
     for split in ('0', '1'):
-        monkeypatch.setenv('CPF_SPLIT', split)
+        tune.set('CPF_SPLIT', split)
         eng = _engine(layer, K, ccz, 'xyz', num_gd_iterations=0)
         init = eng.initial_angles(0, 256)
         first = eng.optimize(init)['regloss'].cpu().numpy()[:, 0]
@@ -512,7 +512,7 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
     both = a['passed'] & b['passed']
     assert (a['cz'][both] == b['cz'][both]).mean() > 0.97
     assert a['cz'][a['passed']].min() == b['cz'][b['passed']].min() == 8
-    monkeypatch.delenv('CPF_SPLIT')
+    tune.unset('CPF_SPLIT')
     eng = _engine(layer, K, ccz, 'xyz', num_gd_iterations=3, loss='relative_phase')
     eng.optimize(eng.initial_angles(0, 8))
     assert eng.last_variant().startswith('layered/')
@@ -521,13 +521,13 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch):
     assert eng.last_variant().startswith('layered/')
 
 
-def test_issue_priority_does_not_change_results(monkeypatch):
+def test_issue_priority_does_not_change_results(monkeypatch, tune):
     """The two-ended kernel raises the issue priority of its longer wave when the launch leaves SIMDs unsaturated
     (cpf_split.h): a scheduling hint only - outputs are bit-identical with it on and off."""
     ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
     res = {}
     for prio in ('0', '1'):
-        monkeypatch.setenv('CPF_PRIO', prio)
+        tune.set('CPF_PRIO', prio)
         eng = _engine([[0, 1], [1, 2]], 12, ccz, 'xyz', num_gd_iterations=300)
         out = eng.optimize(eng.initial_angles(3, 200))
         assert eng.last_variant().startswith('split/')
@@ -536,7 +536,7 @@ def test_issue_priority_does_not_change_results(monkeypatch):
         assert np.array_equal(res['0'][k], res['1'][k]), k
 
 
-def test_shipped_jit_cache_needs_no_compiler(monkeypatch):
+def test_shipped_jit_cache_needs_no_compiler(monkeypatch, tune):
     """The reference's tutorial shape that has no ahead-of-time kernel (4-qubit star, tutorial/results/toff4_star) runs
     from the code objects `python -m cpflow_amd.build --precompile` shipped in cpflow_amd/jit_cache: with run-time
     compilation forbidden the launch still uses the specialised kernel built by hipcc, and this process compiles nothing."""
@@ -575,17 +575,17 @@ DENSE_CASES = [
 
 
 @pytest.mark.parametrize('layer,K,rot,ent,lw,how', DENSE_CASES)
-def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypatch):
+def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypatch, tune):
     """The dense-block kernel (cpf_dense.h: one 4x4 matrix per entangling block on a register-resident qubit pair, lane
     qubits exchanged in and out with v_permlane swaps, angle gradients from the 4x4 environment) against the float64
     oracle over a short Adam run with history, with the penalty on and with a frozen mask; every layout variant."""
     n = max(max(p) for p in layer) + 1
     target = _rand_unitary(n, 5)
     T, S = 12, 5
-    monkeypatch.setenv('CPF_DENSE', '1')
-    monkeypatch.setenv('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
+    tune.set('CPF_DENSE', '1')
+    tune.set('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
     if lw is not None:
-        monkeypatch.setenv('CPF_DENSE_LW', lw)
+        tune.set('CPF_DENSE_LW', lw)
     kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
     orc = Oracle(layer, K, target, rot, **kw)
     eng = _engine(layer, K, target, rot, **kw)
@@ -607,7 +607,7 @@ def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypa
     frozen[1::2, ::5] = 1
     outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
     assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
-    monkeypatch.setenv('CPF_DENSE', '0')                  # the gate-by-gate kernels on the same inputs
+    tune.set('CPF_DENSE', '0')                  # the gate-by-gate kernels on the same inputs
     eng0 = _engine(layer, K, target, rot, **kw)
     out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
     assert not eng0.last_variant().startswith('dense')

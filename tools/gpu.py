@@ -3,7 +3,7 @@
 
     python tools/gpu.py perf [cfg2 cfg3 cfg4 cfg5 n5 ...]      kernel time (HIP events) of the optimise launch; env T, FIRST=1
     python tools/gpu.py one <cfg> [S] [T]                      one warm-up + one launch (for rocprofv3 passes)
-    python tools/gpu.py knobs <cfg> <S> "K=V,..." "K=V,..."    same-process A/B over the library's environment knobs
+    python tools/gpu.py knobs <cfg> <S> "K=V,..." "K=V,..."    same-process A/B over the library's tuning switches (cpf_set_tuning)
     python tools/gpu.py ablib libA.so libB.so [cfg]            same-box A/B of two builds (alternating processes, CPF_LIB)
     python tools/gpu.py agree <KNOB> [cfg2|cfg3]               two settings of a knob: agreement on short runs + timing over S
     python tools/gpu.py fuzz [n_cases] [seed]                  random layers / block counts / rotation strings vs the f64 oracle
@@ -42,8 +42,21 @@ def configs():
     return c
 
 
+TUNING = ('CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_DENSE', 'CPF_DENSE_LW',
+          'CPF_DENSE_SPECIALISED', 'CPF_MFMA', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3')
+
+
+def sync_tuning():
+    """This tool keeps its A/B switches in os.environ; the release library does not read them from there, so they are
+    handed over through cpf_set_tuning before every plan creation / launch."""
+    from cpflow_amd import _ffi
+    for k in TUNING:
+        _ffi.set_tuning(k, os.environ.get(k))
+
+
 def engine(cfg, T=None, **kw):
     from cpflow_amd.engine import TemplateEngine
+    sync_tuning()
     layer, K, tgt, Ss = configs()[cfg]
     return TemplateEngine(layer, K, tgt, kw.pop('rot', 'xyz'), num_gd_iterations=int(os.environ.get('T', '2000')) if T is None else T, **kw), Ss
 
@@ -95,6 +108,7 @@ def cmd_knobs(args):
             for kv in c.split(','):
                 k, v = kv.split('=')
                 os.environ[k] = v
+            sync_tuning()
             out = eng.optimize(init)
             torch.cuda.synchronize()
             res[c].append(eng.last_kernel_ms())
@@ -176,6 +190,7 @@ def cmd_fuzz(args):
             for k in ('CPF_PSTORE', 'CPF_KSPEC', 'CPF_JIT_K', 'CPF_SPLIT'):
                 os.environ.pop(k, None)
             os.environ.update(v)
+            sync_tuning()
             eng = TemplateEngine(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent, loss=loss)
             out = {k: x.cpu().numpy() for k, x in eng.optimize(init, frozen=frozen, keep_history=True).items() if x is not None}
             e0 = np.abs(out['history_regloss'][:3, 0] - ref['history_loss'][:, 0]).max()
@@ -201,6 +216,7 @@ def cmd_fix4(_args):
         for k in ('CPF_FORCE_GENERIC', 'CPF_LW', 'CPF_DENSE'):
             os.environ.pop(k, None)
         os.environ.update(env)
+        sync_tuning()
         eng = TemplateEngine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
         out = {k: v.cpu().numpy() for k, v in eng.optimize(eng.initial_angles(int(g['seed']), S)).items() if v is not None}
         passed = set(np.flatnonzero(out['passed']).tolist())
