@@ -8,6 +8,8 @@ all-gather the per-sample summaries.  value = (samples x iterations x steps) / w
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config cfg3 --gpus 8      # north_star's 8-GPU configurations: cfg3 (4096 samples), cfg5 (8192)
+    python bench.py --config cfg5 --gpus 8
 
 Started WITHOUT torchrun and with --gpus N > 1, this process only launches N fresh worker
 processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child) before
@@ -49,12 +51,36 @@ def launch_ranks(n):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that fails or hangs must not hang the parent: poll all ranks, end everyone as soon as one exits non-zero or
+    # the deadline passes (CPF_BENCH_RANK_TIMEOUT seconds, default 1500), and return a non-zero code
+    import threading
+    deadline = time.time() + float(os.environ.get('CPF_BENCH_RANK_TIMEOUT', '1500'))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes, failed = [None] * n, None
+    while any(c is None for c in codes) and failed is None:
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0):
+                    failed = f'rank {r} exited with code {codes[r]}'
+        if time.time() > deadline:
+            failed = f'ranks still running after the deadline: {[r for r, c in enumerate(codes) if c is None]}'
+        time.sleep(0.2)
+    if failed:
+        print(f'[bench] {failed}; stopping the other ranks', file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    out = b''.join(chunks)
     for line in out.decode().splitlines():                # the one JSON line to stdout; library chatter (gloo) to stderr
         print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return 1 if failed else 0
 
 
 def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
@@ -88,6 +114,34 @@ def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
                       f'{"-march=native" if lib_path else "portable -O3"}), {dt:.1f} s'}
 
 
+def other_configs(workloads, TemplateEngine, torch, launches=3):
+    """The other BASELINE configurations' per-GPU shares (cfg3: 512 samples, cfg4: 2048, cfg5: 1024) measured in this same
+    process after the headline run: one warm-up and `launches` timed launches each (HIP events on the launch stream), so
+    that the driver's own run records them too.  They never enter `value`."""
+    rows = {}
+    for name in ('cfg3', 'cfg4', 'cfg5'):
+        wl = workloads.CONFIGS[name]
+        try:
+            eng = TemplateEngine(wl.layer, wl.num_cp_gates, wl.target, wl.rotation_gates, r=wl.r, num_gd_iterations=wl.num_gd_iterations)
+            S = wl.samples_per_gpu
+            init = eng.initial_angles(wl.seed, S * wl.gpus, 0, S)
+            eng.optimize(init)
+            torch.cuda.synchronize()
+            eng.event_log = []
+            for _ in range(launches):
+                out = eng.optimize(init)
+            ms, all_ms = eng.mean_kernel_ms()
+            tf = eng.flops_per_sample_step * S * wl.num_gd_iterations / (ms * 1e-3) / 1e12
+            rows[name] = {'workload': f'{wl.title}, num_cp_gates={wl.num_cp_gates}, num_samples={S} (one GPU\'s share of {S * wl.gpus})',
+                          'kernel': eng.last_variant(), 'kernel_ms': ms, 'kernel_ms_all': all_ms,
+                          'sample_steps_per_s': S * wl.num_gd_iterations / (ms * 1e-3), 'tflops': tf, 'frac': tf / FP32_PEAK_TFLOPS,
+                          'flop_per_sample_step': eng.flops_per_sample_step, 'passed_entry_loss': int(out['passed'].sum())}
+            eng.close()
+        except Exception as e:          # reported, never required
+            rows[name] = {'error': str(e)[:300]}
+    return rows
+
+
 def stored_traffic(config, samples_per_gpu):
     """HBM bytes per launch from the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this
     configuration (profiles/r*_<config>_pmc_summary.json; counters need their own profiler passes, so they cannot be
@@ -113,6 +167,7 @@ def main():
                     help='BASELINE.json configuration (default: configs[1], the one the metric is quoted on)')
     ap.add_argument('--samples-per-gpu', type=int, default=None, help="override the configuration's per-GPU sample count")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the extra.other_configs block of the cfg2 line')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -136,10 +191,12 @@ def main():
                      f'path can be rehearsed with CPF_ONE_DEVICE=1 CPF_DIST_BACKEND=gloo')
         torch.cuda.set_device(local_rank)
         backend = os.environ.get('CPF_DIST_BACKEND', 'gloo' if one_device else 'nccl')
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get('CPF_DIST_TIMEOUT', '600')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {n_gpus} rank(s)', file=sys.stderr)
@@ -184,6 +241,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # what torch.distributed saw: backend, world size, and the distinct devices behind the ranks (every rank contributes
+    # its device's UUID / PCI bus id), so that a reader can tell N ranks on N devices from N ranks on one
+    props = torch.cuda.get_device_properties(eng.device)
+    me = {'rank': rank, 'device_index': eng.device.index, 'uuid': str(getattr(props, 'uuid', '')),
+          'pci_bus_id': f'{getattr(props, "pci_domain_id", 0):04x}:{getattr(props, "pci_bus_id", 0):02x}:{getattr(props, "pci_device_id", 0):02x}',
+          'name': props.name, 'host': socket.gethostname()}
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        dist_info = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks': everyone,
+                     'distinct_devices': len({(e['host'], e['uuid'] or e['pci_bus_id'], e['device_index']) for e in everyone})}
+    else:
+        dist_info = {'backend': None, 'world_size': 1, 'ranks': [me], 'distinct_devices': 1}
+
     if rank == 0:
         value = S_total * T * args.steps / elapsed
         flops = eng.flops_per_sample_step                      # 3 N^2 (32 K + 16 n) + 20 P (84,804 at config 2)
@@ -212,6 +283,9 @@ def main():
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,
                     'frac': alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        line['distributed'] = dist_info
+        if n_gpus == 1 and args.config == 'cfg2' and not args.no_other_configs:
+            line['extra'] = {'other_configs': other_configs(workloads, TemplateEngine, torch)}
         if not args.no_cpu_baseline and n_gpus == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(wl, layer, K, target, rot, T, r)

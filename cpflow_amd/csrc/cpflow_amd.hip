@@ -632,7 +632,7 @@ const char* cpf_last_error(void) { return g_err; }
 
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW",
-                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_MFMA", "CPF_RELABEL", "CPF_FORCE_GENERIC",
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_RELABEL", "CPF_FORCE_GENERIC",
                                         "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)

@@ -2,12 +2,21 @@
 cpflow/main.py:695-864).
 
 The reference drives hyperopt's `fmin(..., algo=tpe.suggest)` one evaluation at a time.  hyperopt is a
-third-party dependency that is not available here, so the suggestion step is an own tree-structured
-Parzen estimator over the same search space (num_cp_gates ~ quniform(min, max, 1), r ~ lognormal(log r_mean,
-r_variance)) with hyperopt's defaults (20 random start-up evaluations, gamma = 0.25, 24 candidates).  The
-suggestion *sequence* therefore differs from hyperopt's (parity unpinned); everything around it
-follows the reference: the objective and its score, the seed chain (verified against stored seeds), saving after
-every evaluation, resuming from stored trials, the scoreboard and the verify-on-improvement logic.
+third-party dependency that is not available here, so the suggestion step is restated over the same search space
+(num_cp_gates ~ quniform(min, max, 1), r ~ lognormal(log r_mean, r_variance)) with hyperopt's defaults (20 random
+start-up evaluations, gamma = 0.25, 24 candidates):
+
+* the 20 START-UP evaluations draw from the prior exactly as hyperopt 0.2.7 does under
+  `fmin(..., rstate=np.random.default_rng(seed_i))` (main.py:801-810): fmin hands `rstate.integers(2**31 - 1)` to
+  `tpe.suggest`, which seeds a fresh `default_rng` with it for `rand.suggest`; the space is evaluated r first
+  (`exp(rng.normal(float32 log r_mean, r_variance))`), then num_cp_gates (`round(rng.uniform(min, max))`).  Pinned:
+  the first 20 (num_cp_gates, r) of both stored adaptive runs (tests/golden/adaptive_*.npz) and the trials the tutorial
+  printed (cells 81, 89) are reproduced exactly (tests/test_host_logic.py);
+* after that an own tree-structured Parzen estimator takes over; its suggestions differ from hyperopt's
+  (parity unpinned beyond the start-up phase).
+
+Everything around it follows the reference: the objective and its score, the seed chain (verified against stored
+seeds), saving after every evaluation, resuming from stored trials, the scoreboard and the verify-on-improvement logic.
 """
 import math
 
@@ -64,11 +73,17 @@ def _sample_parzen(rng, mus, sig, n, lo=None, hi=None):
     return np.array(out)
 
 
-def suggest(rng, history, k_min, k_max, r_mean, r_variance):
-    """One (num_cp_gates, r) suggestion.  history: list of (num_cp_gates, r, score)."""
+def suggest(random_seed, history, k_min, k_max, r_mean, r_variance):
+    """One (num_cp_gates, r) suggestion for the trial whose link of the seed chain is random_seed.
+    history: list of (num_cp_gates, r, score)."""
+    # fmin(rstate=default_rng(random_seed)) -> algo(..., seed=rstate.integers(2**31 - 1)) -> default_rng(seed)
+    rng = np.random.default_rng(int(np.random.default_rng(int(random_seed)).integers(2 ** 31 - 1)))
+
     def prior():
-        k = int(round(rng.uniform(k_min - 0.5, k_max + 0.5)))
-        return min(max(k, k_min), k_max), float(math.exp(rng.normal(math.log(r_mean), r_variance)))
+        # hp.lognormal('r', jnp.log(r_mean), r_variance): the mean arrives as a float32; r is drawn before num_cp_gates
+        r = float(np.exp(rng.normal(float(np.log(np.float32(r_mean))), r_variance, size=(1,))[0]))
+        k = int(np.round(rng.uniform(k_min, k_max, size=(1,))[0]))           # scope.int(hp.quniform(..., 1))
+        return k, r
 
     finite = [(k, r, s) for k, r, s in history]
     if len(finite) < N_STARTUP:
@@ -137,9 +152,8 @@ def run_adaptive(syn, options, save_results=True, save_to=''):
         print('\n' + '-' * 42)
         print(f'iteration {i}/{options.max_evals}')
         random_seed = prng.next_adaptive_seed(random_seed)
-        rng = np.random.default_rng(int(random_seed))
         history = [(t['num_cp_gates'], t['r'], t['loss']) for t in trials.results]
-        k, r = suggest(rng, history, options.min_num_cp_gates, options.max_num_cp_gates, options.r_mean,
+        k, r = suggest(random_seed, history, options.min_num_cp_gates, options.max_num_cp_gates, options.r_mean,
                        options.r_variance)
         last = evaluate(random_seed, k, r)
         trials.append({'num_cp_gates': k, 'r': r}, last)

@@ -56,3 +56,22 @@ def test_gather_equals_single_rank(size, S):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(size)]
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """`python bench.py --gpus 2` started without torchrun on a box with fewer than 2 GPUs (here: none): every rank exits
+    with an error before rendezvous, and the parent must return non-zero promptly instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'CPF_ONE_DEVICE')}
+    env['CPF_BENCH_RANK_TIMEOUT'] = '120'
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this box has two GPUs: the ranks would run')
+    assert out.returncode != 0 and not out.stdout.strip().startswith('{') and time.time() - t0 < 200
+    assert 'visible GPU' in out.stderr or 'exited with code' in out.stderr

@@ -126,44 +126,112 @@ def _chi2_two_sample(a, b, bins):
     return float((((ka * ha - kb * hb) ** 2) / (ha + hb)).sum()), int(m.sum() - 1)
 
 
-def test_config2_unbiased_against_float32_oracle():
-    """Config 2 at full size (1024 samples x 2000 iterations) on the kernel and on the float32 oracle (same initial
-    angles, all host cores).  Individual runs are chaotic (lr 0.1 for 2000 steps), so the comparison is statistical: it
-    would catch a systematic drift from fast_sincos, the rcp / sqrt Adam step, -fno-signed-zeros or a wrong gradient
-    scale, none of which a short-run test sees.  Bounds: pass count within 3 sigma of a binomial with the pooled rate;
-    CZ-count histograms of the converged samples compatible (two-sample chi-square below the 99.9 % quantile); quantiles
-    of the best regularised loss within 2e-4 (a tenth of one CZ-equivalent of penalty, r * 2 = 1.1e-3); paired: >= 95 % of
-    the samples get the same pass flag and >= 85 % of the commonly converged ones the same CZ count."""
-    from cpflow_amd import workloads
-    wl = workloads.CONFIGS['cfg2']
-    S, T = wl.samples_per_gpu, wl.num_gd_iterations
+def _ks_two_sample_p(a, b):
+    from scipy.stats import ks_2samp
+    return float(ks_2samp(a, b).pvalue)
+
+
+def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_tol, expect_variant=None, S_total=None):
+    """One BASELINE configuration at full length (S samples x 2000 iterations) on the kernel and on the float32 oracle
+    (same initial angles, all host cores).  Individual runs are chaotic (lr 0.1 for 2000 steps), so the comparison is
+    statistical: it would catch a systematic drift from fast_sincos, the rcp / sqrt Adam step, -fno-signed-zeros, a wrong
+    gradient scale or a biased gradient of one kernel family, none of which a short-run test sees.  Bounds: pass count
+    within 3 sigma of a binomial with the pooled rate; >= 95 % of the samples get the same pass flag; CZ-count histograms
+    of the converged samples compatible (two-sample chi-square below the 99.9 % quantile) and >= same_cz_min of the
+    commonly converged samples with the same CZ count; quantiles of the best regularised loss over ALL samples within
+    q_tol; median paired difference below pair_tol."""
+    T = wl.num_gd_iterations
     eng = _engine(wl)
-    init = eng.initial_angles(wl.seed, S)
+    init = eng.initial_angles(wl.seed, S_total or S, 0, S)
     out = _np(eng.optimize(init))
+    variant = eng.last_variant()
+    if expect_variant:
+        assert variant.startswith(expect_variant), variant
     orc = Oracle(wl.layer, wl.num_cp_gates, wl.target, wl.rotation_gates, num_gd_iterations=T, r=wl.r)
     ref = orc.run(init.cpu().numpy(), np.float32, nthreads=int(orc.lib.cpfo_max_threads()))
     pg, po = out['passed'], ref['passed'].astype(bool)
     p = (pg.sum() + po.sum()) / (2 * S)
     sigma = np.sqrt(2 * S * p * (1 - p))                      # sd of the difference of two binomial counts
-    print(f'passed: kernel {pg.sum()} oracle {po.sum()} (3 sigma = {3 * sigma:.1f}); same flag {np.mean(pg == po):.3f}')
-    assert abs(int(pg.sum()) - int(po.sum())) <= 3 * sigma
+    print(f'[{wl.name} {variant}] passed: kernel {pg.sum()} oracle {po.sum()} (3 sigma = {3 * sigma:.1f}); same flag {np.mean(pg == po):.3f}')
+    assert abs(int(pg.sum()) - int(po.sum())) <= max(3 * sigma, 1)
     assert np.mean(pg == po) >= 0.95
     both = pg & po
-    same_cz = np.mean(out['cz'][both] == ref['cz'][both])
-    stat, dof = _chi2_two_sample(out['cz'][pg], ref['cz'][po], bins=list(range(6, 14)))
-    from scipy.stats import chi2
-    print(f'cz: same on {same_cz:.3f} of the commonly converged; chi2 {stat:.1f} (dof {dof}, 99.9 % = {chi2.ppf(0.999, dof):.1f}); '
-          f'mean {out["cz"][pg].mean():.3f} vs {ref["cz"][po].mean():.3f}; min {out["cz"][pg].min()} vs {ref["cz"][po].min()}')
-    assert same_cz >= 0.85
-    assert stat < chi2.ppf(0.999, dof)
-    assert abs(out['cz'][pg].mean() - ref['cz'][po].mean()) < 0.1 and out['cz'][pg].min() == ref['cz'][po].min()
+    if both.sum() >= 50:
+        same_cz = np.mean(out['cz'][both] == ref['cz'][both])
+        stat, dof = _chi2_two_sample(out['cz'][pg], ref['cz'][po], bins=cz_bins)
+        from scipy.stats import chi2
+        print(f'cz: same on {same_cz:.3f} of the commonly converged; chi2 {stat:.1f} (dof {dof}, 99.9 % = {chi2.ppf(0.999, dof):.1f}); '
+              f'mean {out["cz"][pg].mean():.3f} vs {ref["cz"][po].mean():.3f}; min {out["cz"][pg].min()} vs {ref["cz"][po].min()}')
+        assert same_cz >= same_cz_min
+        assert stat < chi2.ppf(0.999, dof)
+        assert abs(out['cz'][pg].mean() - ref['cz'][po].mean()) < 0.1 * (1 if same_cz_min >= 0.85 else 3)
+        assert abs(int(out['cz'][pg].min()) - int(ref['cz'][po].min())) <= (0 if same_cz_min >= 0.85 else 1)
+    # distribution of the best regularised loss over ALL samples: two-sample Kolmogorov-Smirnov, and quantile by quantile -
+    # either the values agree to q_tol, or (where the distribution has a gap between two basins, e.g. config 4's q0.9 between
+    # the 0.137 and 0.150 clusters) the kernel's quantile sits at a statistically compatible position of the oracle's CDF
+    ks_p = _ks_two_sample_p(out['regloss'][:, 1], ref['regloss'][:, 1])
+    print(f'best regloss: two-sample KS p = {ks_p:.3f}')
+    assert ks_p > 1e-3
     for q in (0.1, 0.25, 0.5, 0.75, 0.9):
-        a, b = np.quantile(out['regloss'][pg, 1], q), np.quantile(ref['regloss'][po, 1], q)
-        print(f'best regloss q{q}: kernel {a:.6f} oracle {b:.6f}')
-        assert abs(a - b) < 2e-4
-    d = np.abs(out['regloss'][both, 1] - ref['regloss'][both, 1])
-    print(f'|d best regloss| over the commonly converged: median {np.median(d):.2e} p90 {np.quantile(d, 0.9):.2e}')
-    assert np.median(d) < 5e-5
+        a, b = np.quantile(out['regloss'][:, 1], q), np.quantile(ref['regloss'][:, 1], q)
+        pos = np.mean(ref['regloss'][:, 1] <= a)
+        band = 3 * np.sqrt(2 * q * (1 - q) / S) + 1.0 / S
+        print(f'best regloss q{q}: kernel {a:.6f} oracle {b:.6f} (oracle CDF at the kernel value {pos:.3f}, band {band:.3f})')
+        assert abs(a - b) < q_tol or abs(pos - q) <= band
+    diff = out['regloss'][:, 1] - ref['regloss'][:, 1]
+    d = np.abs(diff)
+    print(f'|d best regloss| over all samples: median {np.median(d):.2e} p90 {np.quantile(d, 0.9):.2e}; '
+          f'median signed {np.median(diff):+.2e}')
+    assert np.median(d) < pair_tol and abs(np.median(diff)) < pair_tol / 2
+    return variant
+
+
+def test_config2_unbiased_against_float32_oracle():
+    """Config 2 at full size (1024 samples x 2000 iterations): quantiles within 2e-4 (a tenth of one CZ-equivalent of
+    penalty, r * 2 = 1.1e-3), >= 85 % of the commonly converged samples with the same CZ count."""
+    from cpflow_amd import workloads
+    wl = workloads.CONFIGS['cfg2']
+    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(6, 14)), 0.85, 2e-4, 5e-5, 'split/aot')
+
+
+def test_config4_unbiased_against_float32_oracle():
+    """Config 4 at full size (4-qubit QFT, 2048 samples x 2000 iterations) on the relabelled one-wave gate-by-gate
+    kernel.  4-qubit runs are more chaotic than 3-qubit ones (tests/test_gpu_synthesis.py, fixture toff4_star_t14:
+    independent roundings of the oracle agree with each other on 84-86 % of the per-sample CZ counts)."""
+    from cpflow_amd import workloads
+    wl = workloads.CONFIGS['cfg4']
+    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(14, 30)), 0.5, 1e-3, 1e-3)
+
+
+def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
+    """The 5-qubit benchmark problem of paper/results/benchmarks/res_4gt13_91 trial 99 (chain, 'xyz', 86 blocks, 617
+    angles, its stored target, seed and r): the first 256 of its 1000 samples over 2000 iterations on the relabelled
+    one-wave layered kernel from the shipped cache against the float32 oracle.  The stored run itself used older penalty
+    constants, so it pins loss and initial angles only (tests/test_gpu_synthesis.py); this is the full-length pin of the
+    5-qubit kernel."""
+    monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
+    g = np.load(os.path.join(GOLD, 'raw_4gt13_xyz_t99.npz'))
+
+    class Trial:
+        name, layer, num_cp_gates, target, rotation_gates = '4gt13 trial 99', g['layer'].tolist(), int(g['num_cp_gates']), g['target'], str(g['rotation_gates'])
+        r, seed, num_gd_iterations = float(g['r']), int(g['seed']), 2000
+    _unbiased_against_float32_oracle(Trial, 256, list(range(40, 80, 4)), 0.3, 2e-3, 2e-3, 'layered/jit(hipcc) waves=1', S_total=int(g['num_samples']))
+
+
+@pytest.mark.parametrize('kernel', ['default', 'dense', 'gate-by-gate'])
+def test_config5_unbiased_against_float32_oracle(kernel, tune):
+    """Config 5 (6 qubits, ring, 60 blocks, SU(64) target): 128 samples x 2000 iterations on the kernel the plan picks,
+    on the dense-block kernel and on the gate-by-gate kernel, each against the float32 oracle.  No run converges
+    (60 blocks cannot reach a generic SU(64)), so the statistics are those of the final losses: a biased gradient of the
+    per-block 4x4 environments would show as a shifted distribution of the best loss after 2000 steps."""
+    from cpflow_amd import workloads
+    wl = workloads.CONFIGS['cfg5']
+    if kernel == 'dense':
+        tune.set('CPF_DENSE', '1')
+    elif kernel == 'gate-by-gate':
+        tune.set('CPF_DENSE', '0')
+    variant = _unbiased_against_float32_oracle(wl, 128, list(range(60, 121)), 0.5, 4e-3, 4e-3)
+    assert variant.split('/')[0] == {'default': variant.split('/')[0], 'dense': 'dense', 'gate-by-gate': 'layered'}[kernel]
 
 
 def test_local_minimums_success_ratios():

@@ -370,3 +370,129 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and '512 total' in line['config']['workload']
     assert line['value'] > 0 and line['roofline']['bound'] == 'valu' and 'cpu_baseline' not in line
+    # the line describes the job torch.distributed ran: here gloo, two ranks, both on the box's one GPU
+    di = line['distributed']
+    assert di['backend'] == 'gloo' and di['world_size'] == 2 and [e['rank'] for e in di['ranks']] == [0, 1] and di['distinct_devices'] == 1
+
+
+def _score(cz_passed, S):
+    """main.py:831-835: -log2 of the mean of 2^-cz over all samples (failed samples contribute 0)."""
+    return float(-np.log2((2.0 ** -np.asarray(cz_passed, dtype=np.float32)).sum() / S)) if len(cz_passed) else float('inf')
+
+
+# (fixture, kernel variant the launch must use, |pass count - stored| allowed, stored passes that must pass here too,
+#  CZ-histogram samples that may move, score tolerance)
+T3_MORE = [
+    # G3, 3 qubits all-to-all, 200 samples: 198 stored; float32 / float64 oracle: 199 passes, all 198 stored ones among them.
+    # Its stored reg values come from older penalty constants (SURVEY App. D), which moves a few CZ counts, not the pass set
+    ('raw_toff3_conn_t99', 'split/', 3, 195, 14, 0.15),
+    # G2 trial 49, 4-qubit star, 500 samples, 7 stored passes (the oracle finds the same 7)
+    ('raw_toff4_star_t49', 'layered/jit(hipcc)', 4, 5, 4, 1.6),
+    # G5, 5-qubit chain 'xyz', 86 blocks, 1000 samples, 39 stored passes.  The stored run used OLDER penalty constants (its
+    # stored reg values are 1.4-1.7 x what penalty.py:44-71 gives at the same angles; SURVEY App. D: "don't pin reg"), and a
+    # heavier penalty leaves fewer runs below entry_loss: the float32 oracle with today's penalty passes 8 of the first 160
+    # samples (5.0 %), the kernel 88 of 1000 (8.8 %), the stored run 39 (3.9 %; 6 of the first 160).  So against the stored
+    # numbers only the order of magnitude is asserted here; the kernel-vs-oracle statistics of this very problem are in
+    # tests/test_gpu_baseline_configs.py::test_stored_5q_trial_unbiased_against_float32_oracle
+    ('raw_4gt13_xyz_t99', 'layered/jit(hipcc)', 70, 0, None, 4.0),
+    # G4, 5 qubits all-to-all 'xz', 57 blocks, 2000 samples, ONE stored pass
+    ('raw_4gt10_xz_t30', 'layered/jit(hipcc)', 12, 0, None, None),
+]
+
+
+@pytest.mark.parametrize('name,variant,dpass,min_common,moved_max,score_tol', T3_MORE, ids=[t[0][4:] for t in T3_MORE])
+def test_T3_more_stored_trials_end_of_run(name, variant, dpass, min_common, moved_max, score_tol, monkeypatch):
+    """Full 2000-iteration runs of the remaining stored trials (3 qubits all-to-all, 4-qubit star, the two 5-qubit
+    benchmark files - the only reference data that exercise the 5-qubit kernels end to end), from the shipped kernel cache
+    (CPF_JIT_FORBID_COMPILE=1).  Bars: the number of samples below entry_loss against the stored number (3 sigma of the
+    difference of two binomial counts where the stored run used today's penalty; Poisson for the single stored pass of
+    G4; order of magnitude for G5, see T3_MORE), the stored passes found again where runs are reproducible (3 qubits), the CZ histogram
+    and the adaptive score main.py:831-835 computes from it."""
+    monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    S, idx = int(g['num_samples']), g['sample_index']
+    eng = _engine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
+    init = eng.initial_angles(int(g['seed']), S)
+    out = _np(eng.optimize(init))
+    assert eng.last_variant().startswith(variant), eng.last_variant()
+    assert (out['params'][idx, 0].view(np.uint32) == g['params'][:, 0].view(np.uint32)).all()   # T0
+    passed = np.flatnonzero(out['passed'])
+    common = len(set(passed.tolist()) & set(idx.tolist()))
+    cz = out['cz'][out['passed']]
+    score = _score(cz, S)
+    print(f'{name} [{eng.last_variant()}]: {len(passed)} passed (stored {len(idx)}, {common} in common); CZ {np.bincount(cz).tolist() if len(cz) else []} '
+          f'vs stored {np.bincount(g["cz"]).tolist()}; score {score:.3f} (stored {float(g["score"]):.3f})')
+    assert abs(len(passed) - len(idx)) <= dpass
+    assert common >= min_common
+    if moved_max is not None:
+        top = max(int(cz.max()), int(g['cz'].max())) + 1
+        moved = np.abs(np.bincount(cz, minlength=top) - np.bincount(g['cz'], minlength=top)).sum() / 2
+        assert moved <= moved_max, moved
+    if score_tol is not None:
+        assert abs(score - float(g['score'])) < score_tol
+    if name == 'raw_4gt13_xyz_t99':          # distribution level: the converged runs use as many CZ gates as the stored ones
+        assert abs(np.median(cz) - np.median(g['cz'])) <= 6 and abs(int(cz.min()) - int(g['cz'].min())) <= 6
+    _check_sizeless(eng, init, out, S)
+
+
+def _check_sizeless(eng, init, out, S):
+    assert (out['regloss'][:, 1] <= out['regloss'][:, 0]).all() and (out['loss'] == out['regloss'] - out['reg']).all()
+    re = _np(eng.loss_and_grad(out['params'][:, 1], with_grad=False))
+    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['K3_ghz_state_preparation', 'K4_relative_phase_toffoli'])
+def test_tutorial_known_answers_K3_K4_custom_losses(name):
+    """Tutorial cells 81 / 89 through the reference-shaped front end with the loss OBJECTS that stand for the tutorial's
+    lambdas: Synthesize(layer, target_state=GHZ) / Synthesize(layer, unitary_loss_func=RelativePhaseLoss(toffoli)),
+    _generate_raw + _evaluate_raw at the (num_cp_gates, r, seed) of the notebook's first productive adaptive trial.  The
+    notebook printed 83 prospective results (52 x 3, 30 x 4, 1 x 5 CZ; score 3.5724) and 100 prospective (score 5.2313);
+    same bars as the CPU oracle test (tests/test_oracle_golden.py)."""
+    from cpflow_amd import RelativePhaseLoss, StaticOptions, Synthesize
+    from test_oracle_golden import check_known_answer, known_answer_case
+    layer, K, r, seed, S, score, cz_ref, target, kind = known_answer_case(GOLD, name)
+    if kind == 1:
+        syn = Synthesize(layer, target_state=target[:, 0], label='GHZ_4q_linear')
+    else:
+        syn = Synthesize(layer, unitary_loss_func=RelativePhaseLoss(target), label='relative_toff3_connected')
+    opts = StaticOptions(num_cp_gates=K, r=r, accepted_num_cz_gates=int(cz_ref.max()), num_samples=S, random_seed=seed)
+    raw = syn._generate_raw(opts)
+    sel = syn._evaluate_raw(raw, opts)
+    check_known_answer(np.array([c for c, _ in sel]), S, score, cz_ref, name + ' (device)')
+    # against the oracle on the same seed: same pass flags, same CZ counts except boundary samples
+    orc = Oracle(layer, K, target, 'xyz', r=r, loss_kind=kind)
+    ref = orc.run(orc.initial_angles(seed, S), np.float32)
+    assert np.mean(raw.passed == ref['passed']) >= 0.97
+    both = raw.passed & ref['passed']
+    assert np.mean(raw.cz[both] == ref['cz'][both]) >= 0.9
+    # the verification stage on the best candidates reaches the tutorial's result: 3 CZ gates, loss ~ 0
+    best = [res for res in sel if res[0] <= 3][:4]
+    ok = [v for v in syn._verify_batch(best, K, opts) if v[0]]
+    assert ok and min(v[1] for v in ok) == 3
+
+
+def test_adaptive_run_against_the_stored_hyperopt_trials(tmp_path):
+    """SURVEY 8 f-4 on the device: Synthesize.adaptive on the tutorial's toff3_chain problem (range [10, 20], 100 samples,
+    seed 0: the range the stored draws imply, tests/test_host_logic.py) for 50 evaluations against the stored run (tutorial/results/toff3_chain, 50 hyperopt
+    trials).  The first 20 evaluations use the reference's own (seed, num_cp_gates, r) (start-up phase, reproduced exactly
+    by cpflow_amd.hyper.suggest), so their scores must be the stored ones up to the run-to-run noise of a score (one
+    boundary sample moving between CZ counts changes it by ~0.01-0.05): >= 17 of 20 within 0.1, all within 0.5.  The
+    remaining 30 come from the own estimator (hyperopt's TPE sequence is not reproduced): the best score reached must
+    lie within the range the stored run explored there."""
+    from cpflow_amd import AdaptiveOptions, Synthesize
+    a = np.load(os.path.join(GOLD, 'adaptive_toff3_chain.npz'))
+    opts = AdaptiveOptions(min_num_cp_gates=10, max_num_cp_gates=20, max_evals=50, num_samples=100, target_num_cz_gates=6)
+    res = Synthesize([[0, 1], [1, 2]], target_unitary=TOFF3, label='toff3_chain').adaptive(opts, save_to=str(tmp_path / 'r' / 'toff3'))
+    tr = res.trials.results
+    assert len(tr) == 50
+    d = []
+    for i in range(20):
+        assert tr[i]['random_seed'] == int(a['seeds'][i]) and tr[i]['num_cp_gates'] == int(a['num_cp_gates'][i])
+        assert abs(tr[i]['r'] / float(a['r'][i]) - 1) < 4e-16
+        d.append(abs(tr[i]['loss'] - float(a['score'][i])))
+    print('start-up scores: |d| sorted', np.round(sorted(d), 3).tolist())
+    assert sum(x < 0.1 for x in d) >= 17 and max(d) < 0.5
+    best, stored = min(t['loss'] for t in tr), a['score']
+    print(f'best score {best:.3f}; stored run: best {stored.min():.3f}, median {np.median(stored):.3f}')
+    assert stored.min() - 0.3 <= best <= np.median(stored)
+    assert min(d.cz_count for d in res.decompositions) <= 8      # the tutorial's run ends with 8 CZ gates on the chain

@@ -15,6 +15,8 @@ Fixture families:
   dec_*   post-verification angle vectors of stored Decomposition objects
           (fixed CP angles + free angles) whose unitary must hit the target.
   adaptive_*  the adaptive seed chain and (num_cp_gates, r, score, cz_counts).
+  known_answers_custom_losses  printed outputs of the executed tutorial for the state-preparation and
+          relative-phase losses (K3 / K4): seed-chain position, (K, r), score, CZ counts.
 """
 import os
 import sys
@@ -232,6 +234,36 @@ def extract_local_minimums():
     print(f'{out}: {len(rows)} records')
 
 
+def extract_known_answers():
+    """Printed outputs of the executed tutorial notebook for the two custom losses: the first
+    adaptive trial that produced prospective results - its position in the seed chain, (num_cp_gates, r), the printed score
+    and the printed CZ counts of the prospective results.  Cell 81: GHZ state preparation, 4 qubits on a line; cell 89:
+    relative-phase Toffoli, 3 qubits all-to-all.  Only numbers are kept."""
+    import json
+    import re
+    nb = json.load(open(os.path.join(REF, 'tutorial', 'CPFlow_tutorial.ipynb')))
+    rows = {}
+    for cell, name in ((81, 'K3_ghz_state_preparation'), (89, 'K4_relative_phase_toffoli')):
+        c = nb['cells'][cell]
+        src = ''.join(c['source'])
+        layer = json.loads(re.search(r'layer = (\[\[.*?\]\])', src).group(1))
+        text = ''.join(''.join(o.get('text', '')) for o in c.get('outputs', []))
+        opts = re.search(r'AdaptiveOptions\((.*?)\)\n', text).group(1)
+        num_samples = int(re.search(r'num_samples=(\d+)', opts).group(1))
+        seed0 = int(re.search(r'random_seed=(\d+)', opts).group(1))
+        its = re.findall(r'iteration (\d+)/\d+\s+num_cp_gates: (\d+), r: ([0-9.e-]+)\s+score: (\S+), cz counts of prospective results: \[(.*?)\]', text)
+        it, K, r, score, counts = next(x for x in its if x[4].strip())
+        seed = seed0
+        for _ in range(int(it) + 1):                     # main.py:798-799: the seed of trial i is the (i+1)-th link of the chain
+            seed = int(prng.next_adaptive_seed(seed)) if hasattr(prng, 'next_adaptive_seed') else None
+        rows[name] = dict(layer=np.array(layer, dtype=np.int32), trial=int(it), seed=np.uint32(seed), num_cp_gates=int(K), r=float(r),
+                          num_samples=num_samples, score=float(score), cz_counts=np.array([int(x) for x in counts.split(',')], dtype=np.int32))
+    out = os.path.join(OUT, 'known_answers_custom_losses.npz')
+    np.savez_compressed(out, **{f'{k}.{f}': v for k, d in rows.items() for f, v in d.items()})
+    for k, d in rows.items():
+        print(f"{out}: {k} trial {d['trial']} seed {d['seed']} K={d['num_cp_gates']} r={d['r']} -> {len(d['cz_counts'])} prospective, score {d['score']}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     extract_raw('tutorial/results/toff3_chain', [19, 49], 'toff3_chain', num_samples=100)  # G1, G1b
@@ -244,6 +276,7 @@ def main():
     extract_decompositions('tutorial/results/toff4_star', 'toff4_star')
     extract_adaptive('tutorial/results/toff3_chain', 'toff3_chain')
     extract_adaptive('tutorial/results/toff4_star', 'toff4_star')
+    extract_known_answers()
     try:
         extract_local_minimums()
     except Exception as e:  # optional family
