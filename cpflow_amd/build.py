@@ -50,6 +50,22 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_variant(name, defines=(), verbose=False):
+    """A/B build: the library compiled with extra -D flags as cpflow_amd/libcpflow_amd.<name>.so (same directory, so that
+    its runtime-specialised kernels find csrc/; select it with CPF_LIB; tools/gpu.py ablib compares two builds)."""
+    out = os.path.join(HERE, f'libcpflow_amd.{name}.so')
+    cflags = [f for f in FLAGS if f != '-shared'] + [f'-D{d}' for d in defines]
+    objs = [(SRC, os.path.join(HERE, 'csrc', f'cpflow_amd.{name}.o'), []), (DENSE_SRC, os.path.join(HERE, 'csrc', f'cpf_dense_aot.{name}.o'), DENSE_FLAGS)]
+    procs = [subprocess.Popen([HIPCC] + cflags + extra + ['-c', '-o', obj, src]) for src, obj, extra in objs]
+    for p in procs:
+        if p.wait():
+            raise RuntimeError(f'variant {name} failed to compile')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + [o for _, o, _ in objs] + ['-lhiprtc'])
+    for _, o, _ in objs:
+        os.unlink(o)
+    return out
+
+
 def precompile_shapes():
     """(layer, rotation strings, block counts, sample counts) of the reference's tutorial / paper runs whose kernels are
     runtime-specialised: the 4-qubit star of tutorial/results/toff4_star, connected / chain layers on 4 and 5 qubits

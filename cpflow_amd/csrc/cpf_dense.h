@@ -39,7 +39,8 @@ namespace cpf {
 // what the host tells the kernel about block b (int4 per block)
 //   x, y : up to two lane<->register exchanges, each (lane_bit << 8) | reg_bit, or -1
 //   z    : (ra | rb << 4) with ra < rb the register bits the 4x4 acts on, | 256 if the placement's first qubit sits at ra
-//          (the lower bit; the block matrix is then built with its index bits exchanged)
+//          (the lower bit; the block matrix is then built with its index bits exchanged); host table only: | 512 / 1024 if the
+//          surface gate of the up / dn qubit is folded into this block, up qubit << 12, dn qubit << 16
 //   w    : index of the block's first gate (the entangler) in the gate program
 struct DenseBlock { int x, y, z, w; };
 
@@ -146,6 +147,9 @@ __device__ __forceinline__ f2 cmul0_conj(f2 a, f2 b) { return pk_fma(f2{a.y, -a.
 // exchange lane bit LB (4 or 5) with register bit RB of a matrix: one v_permlane{16,32}_swap per 32-bit register pair
 template <int E, int LB, int RB>
 __device__ __forceinline__ void swap_lane_reg(f2 (&x)[E]) {
+#ifdef CPF_EXP_NOSWAP             // timing experiment only (wrong results)
+    return;
+#endif
 #pragma unroll
     for (int e0 = 0; e0 < E; e0++) {
         if (e0 & (1 << RB)) continue;
@@ -270,6 +274,10 @@ __device__ __forceinline__ void dense_backward(f2 (&p)[E], f2 (&c)[E], const f2 
 // pass, nothing else); held in scalar registers instead the compiler builds every (-im, im) and (-y, x) pair with two
 // extra VALU operations (measured: +37 % instructions in the forward sweep).
 __device__ __forceinline__ void load_block_matrix(const float* gm, f2 (&g)[16]) {
+#ifdef CPF_EXP_NOGLOAD            // timing experiment only (wrong results): every block reads block 0's matrix, hoistable
+    extern __shared__ __attribute__((aligned(16))) float cpf_exp_smem[];
+    gm = cpf_exp_smem + 64;
+#endif
     const float4* gp = reinterpret_cast<const float4*>(gm);
 #pragma unroll
     for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
@@ -386,6 +394,10 @@ __device__ __forceinline__ int dense_env_dst16(int lane) {
     return 4 * (2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
 }
 __device__ __forceinline__ void dense_env_reduce16(const f2 (&m)[8], float* dst, int dst_lane) {
+#ifdef CPF_EXP_NOREDUCE           // timing experiment only (wrong results): one add tree per lane, no cross-lane traffic
+    dst[dst_lane] = ((m[0].x + m[1].y) + (m[2].x + m[3].y)) + ((m[4].x + m[5].y) + (m[6].x + m[7].y));
+    return;
+#endif
     float w[8], u[4];
 #pragma unroll
     for (int r = 0; r < 8; r++) {                        // bit 5: values 2r (low half), 2r + 1 (high half); m[r] = (v[2r], v[2r + 1])
@@ -431,7 +443,10 @@ struct DenseLds {
 };
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot; };
+// surf_mask: qubits whose surface gate Rz Rx Rz the sweeps apply gate by gate; every other qubit's surface gate is folded
+// into the first block that touches it (cpf_dense_math.h; DenseBlock::z bits 9 / 10), which removes 3 x 18 rotations of
+// the full state per step (config 5: 6.4 % of the step, measured by leaving them out)
+struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot, surf_mask; };
 
 // UD... = the layer as (up, dn) pairs (block b sits on pair b mod length): the block loops are then straight-line code per
 // layer with compile-time register bits and exchanges.  Empty UD: any circuit, every block dispatched through the table.
@@ -502,6 +517,14 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         };
     };
 
+    // (cos, sin) of surface rotation k of the block's up (side 0) / dn (side 1) qubit: gate 3 q + k of the program
+    auto surf_rec = [&](int qu, int qd) {
+        return [rec, qu, qd](int side, int k, float& c, float& s) {
+            const float4 r = rec[3 * (side ? qd : qu) + k];
+            c = r.x; s = r.y;
+        };
+    };
+
     f2 psi[E], cot[E];
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
@@ -514,7 +537,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         for (int b = tid; b < K; b += THREADS) {
             const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
             dense::cx Gb[4][4];
-            dense::block_matrix(Gb, block_rec(g0), NR);
+            dense::block_matrix(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
             const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
             float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
 #pragma unroll
@@ -533,6 +556,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         for (int e = 0; e < E; e++) psi[e] = f2{(L::row_index(lane_i, e) == col_i) ? 1.f : 0.f, 0.f};
         static_for([&](auto qq) __attribute__((always_inline)) {       // surface gate on qubit q: Rz(t2) Rx(t1) Rz(t0), main.py:122-124
             constexpr int Q = decltype(qq)::value;
+            if (!((da.surf_mask >> Q) & 1)) return;                  // folded into the first block that touches the qubit
             const float4 r0 = rec[3 * Q], r1 = rec[3 * Q + 1], r2 = rec[3 * Q + 2];
             // a lane qubit borrows register bit 0 (qubit NRR-1) for its three gates
             constexpr int BIT = L::on_lane(Q) ? 0 : L::reg_bit(Q);
@@ -555,25 +579,38 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             }
         } else {
             int b = 0;
-            auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = decltype(jj)::value;
-                constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
-                constexpr int RA = ent.z & 15, RB = (ent.z >> 4) & 15;
-                // the exchange stays in place between two blocks of the layer that make the same one (not across the layer's end)
-                constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J - 1, J), KEEP = dense_same_swap<L>(PL::v, LL, J, J + 1);
-                f2 g[16];
-                load_block_matrix(smem + lds.gm + 32 * b, g);
-                if constexpr (ent.x >= 0 && !KEPT) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
-                if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
-                dense_apply<E, RA, RB, false>(psi, g);
-                if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
-                if constexpr (ent.x >= 0) {
-                    if (!KEEP || b + 1 >= K) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);       // the last block of the circuit always exchanges back
-                }
-                b++;
+            // Forward sweep, one layer at a time.  The matrix of the NEXT block of the layer is fetched (eight broadcast LDS
+            // reads) before the arithmetic of the current one - C does not exist yet, so its registers are free for a second
+            // buffer - and only the first block of a layer waits for its matrix (measured: the exposed reads of all blocks
+            // cost 6.5 % of config 5's step).
+            auto fwd_layer = [&](auto tail) __attribute__((always_inline)) {
+                constexpr bool TAIL = decltype(tail)::value != 0;        // the truncated last layer: blocks while b < K
+                f2 ga[16], gb[16];
+                if (!TAIL || b < K) load_block_matrix(smem + lds.gm + 32 * b, ga);
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jj)::value;
+                    constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
+                    constexpr int RA = ent.z & 15, RB = (ent.z >> 4) & 15;
+                    // the exchange stays in place between two blocks of the layer that make the same one (not across the layer's end)
+                    constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J - 1, J), KEEP = dense_same_swap<L>(PL::v, LL, J, J + 1);
+                    auto body = [&](f2 (&g)[16], f2 (&gnext)[16]) __attribute__((always_inline)) {
+                        if constexpr (J + 1 < LL) { if (!TAIL || b + 1 < K) load_block_matrix(smem + lds.gm + 32 * (b + 1), gnext); }
+                        __builtin_amdgcn_sched_barrier(0);               // the reads stay here: the scheduler would sink them to their first use
+                        if constexpr (ent.x >= 0 && !KEPT) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                        if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                        dense_apply<E, RA, RB, false>(psi, g);
+                        if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                        if constexpr (ent.x >= 0) {
+                            if (!KEEP || b + 1 >= K) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);       // the last block of the circuit always exchanges back
+                        }
+                        b++;
+                    };
+                    if (TAIL && b >= K) return;
+                    if constexpr (J & 1) body(gb, ga); else body(ga, gb);
+                }, typename make_iseq<LL>::type{});
             };
-            for (int full = K / LL; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
-            static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); }, typename make_iseq<LL>::type{});
+            for (int full = K / LL; full > 0; full--) fwd_layer(ic<0>{});
+            if (b < K) fwd_layer(ic<1>{});
         }
 
         // ================= loss (matrix_utils.py:35-42) and penalty (main.py:563-564)
@@ -636,8 +673,10 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                 else cot[e] = cmul(f2{t.x, t.y}, f2{fr, fi});
             }
         }
-        // one block of the backward sweep on register bits RA < RB (psi and C already hold the pair in registers)
-        auto bwd_block = [&](auto ra, auto rb, const f2 (&g)[16], int b) __attribute__((always_inline)) {
+        // one block of the backward sweep on register bits RA < RB (psi and C already hold the pair in registers).
+        // prefetch(g): called once the last use of the block's matrix has been issued - the layer-specialised sweep reads the
+        // next block's matrix into the same registers there, under the environment reduction and the exchanges that follow.
+        auto bwd_block = [&](auto ra, auto rb, f2 (&g)[16], int b, auto&& prefetch) __attribute__((always_inline)) {
             constexpr int RA = decltype(ra)::value, RB = decltype(rb)::value;
             if constexpr (HALVES) {
                 f2 m[8];
@@ -648,12 +687,14 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) m[i] = f2{0.f, 0.f};
                 dense_backward<E, RA, RB, 2>(psi, cot, g, m);
+                prefetch(g);
                 dense_env_reduce16(m, env_w + 32 * b + 16, env_dst);
             } else {
                 f2 m[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) m[i] = f2{0.f, 0.f};
                 dense_backward<E, RA, RB, 0>(psi, cot, g, m);
+                prefetch(g);
                 dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
             }
         };
@@ -664,33 +705,42 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                 load_block_matrix(smem + lds.gm + 32 * b, g);
                 do_swap<L>(psi, sx); do_swap<L>(cot, sx);
                 do_swap<L>(psi, sy); do_swap<L>(cot, sy);
-                CPF_PAIR_SWITCH(pair, (bwd_block(ic<RA>{}, ic<RB>{}, g, b)));
+                CPF_PAIR_SWITCH(pair, (bwd_block(ic<RA>{}, ic<RB>{}, g, b, [](f2 (&)[16]) {})));
                 do_swap<L>(psi, sy); do_swap<L>(cot, sy);
                 do_swap<L>(psi, sx); do_swap<L>(cot, sx);
             }
         } else {
             int b = K - 1;
-            auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = LL - 1 - decltype(jj)::value;
-                constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
-                // mirror image of the forward sweep: block J + 1 (swept just before) leaves the exchange in place unless it
-                // was the last block of the circuit's own (b + 1 == K: nothing was swept before this block)
-                constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J, J + 1), KEEP = dense_same_swap<L>(PL::v, LL, J - 1, J);
+            // one layer, last block first; TAIL: the truncated last layer of the circuit (swept first), blocks J < K % LL only
+            auto bwd_layer = [&](auto tail) __attribute__((always_inline)) {
+                constexpr bool TAIL = decltype(tail)::value != 0;
+                const int tail_len = K % LL;
                 f2 g[16];
-                load_block_matrix(smem + lds.gm + 32 * b, g);
-                if constexpr (ent.x >= 0) {
-                    if (!KEPT || b + 1 >= K) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
-                }
-                if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
-                bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, g, b);
-                if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
-                if constexpr (ent.x >= 0 && !KEEP) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
-                b--;
+                load_block_matrix(smem + lds.gm + 32 * b, g);            // the layer's first matrix: the only exposed read of the layer
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = LL - 1 - decltype(jj)::value;
+                    if (TAIL && J >= tail_len) return;
+                    constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
+                    // mirror image of the forward sweep: block J + 1 (swept just before) leaves the exchange in place unless it
+                    // was the last block of the circuit's own (b + 1 == K: nothing was swept before this block)
+                    constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J, J + 1), KEEP = dense_same_swap<L>(PL::v, LL, J - 1, J);
+                    if constexpr (ent.x >= 0) {
+                        if (!KEPT || b + 1 >= K) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                    }
+                    if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
+                    bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, g, b, [&](f2 (&gg)[16]) __attribute__((always_inline)) {
+                        if constexpr (J > 0) {
+                            load_block_matrix(smem + lds.gm + 32 * (b - 1), gg);
+                            __builtin_amdgcn_sched_barrier(0);           // the reads stay here (the scheduler would sink them to their first use)
+                        }
+                    });
+                    if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
+                    if constexpr (ent.x >= 0 && !KEEP) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
+                    b--;
+                }, typename make_iseq<LL>::type{});
             };
-            const int tail = K % LL;                         // blocks beyond the last whole layer come first
-            static_for([&](auto jj) __attribute__((always_inline)) { if (LL - 1 - decltype(jj)::value < tail) bwd_step(jj); },
-                       typename make_iseq<LL>::type{});
-            for (int full = K / LL; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
+            if (K % LL) bwd_layer(ic<1>{});                  // blocks beyond the last whole layer come first
+            for (int full = K / LL; full > 0; full--) bwd_layer(ic<0>{});
         }
         {   // surface gates, backwards: gradient right after each gate, then un-apply it from psi and C
             float ds[8 * NBATCH];
@@ -698,6 +748,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             for (int k = 0; k < 8 * NBATCH; k++) ds[k] = 0.f;
             static_for([&](auto qq) __attribute__((always_inline)) {
                 constexpr int Q = NQ - 1 - decltype(qq)::value;
+                if (!((da.surf_mask >> Q) & 1)) return;
                 const float4 r0 = rec[3 * Q], r1 = rec[3 * Q + 1], r2 = rec[3 * Q + 2];
                 constexpr int BIT = L::on_lane(Q) ? 0 : L::reg_bit(Q);
                 if constexpr (L::on_lane(Q)) { swap_lane_reg<E, L::lane_bit(Q), 0>(psi); swap_lane_reg<E, L::lane_bit(Q), 0>(cot); }
@@ -738,9 +789,12 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                     const float2 gv = *reinterpret_cast<const float2*>(smem + lds.gm + 32 * b + 2 * (4 * ii + jj));
                     Gb[i][j] = dense::mk(gv.x, gv.y);
                 }
-            dense::block_gradient(gw + g0, Gb, Mb, block_rec(g0), NR);     // gate g0 + i carries angle i of the block
+            const int qu = (z >> 12) & 15, qd = (z >> 16) & 15;
+            // gate g0 + i carries angle i of the block; a folded surface gate's angles are gates 3 q .. 3 q + 2
+            dense::block_gradient(gw + g0, Gb, Mb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec(qu, qd), gw + 3 * qu, gw + 3 * qd);
         }
         for (int g = tid; g < NS; g += THREADS) {
+            if (!((da.surf_mask >> (g / 3)) & 1)) continue;              // written by the block the gate is folded into
             float s = 0.f;
             for (int w = 0; w < WPS; w++) {
                 const float4 gp = *reinterpret_cast<const float4*>(smem + lds.gsurf + w * NBATCH * 32 + 32 * (g / 8) + 4 * (g % 8));
@@ -799,7 +853,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
 }
 
 template <int NQ, int LW, int... UD>
-__global__ __launch_bounds__(64 << LW, (DLay<NQ, LW>::E >= 32 ? 1 : 2)) void k_cp_dense(const DenseArgs da) {
+__global__ __launch_bounds__(64 << LW, ((DLay<NQ, LW>::E >= 32 && sizeof...(UD) == 0) ? 1 : 2)) void k_cp_dense(const DenseArgs da) {
     dense_body<NQ, LW, UD...>(da);
 }
 

@@ -4,7 +4,8 @@
 // One entangling block of the template (cpflow/main.py:69-82) acts on its qubit pair as the 4x4 matrix
 //     G = A_m ... A_2 A_1 E,     E = CP(a) | CZ | CX,   A_1 = R_g0(up), A_2 = R_g0(dn), A_3 = R_g1(up), ...
 // in the basis index 2 * up + dn (up = first qubit of the placement, gates.py / circuit_assembly.py:16-28).
-//   block_matrix      G from the block's (cos, sin) records                         [before the forward sweep]
+//   block_matrix      G from the block's (cos, sin) records (optionally with the surface gates of its qubits folded in:
+//                     G' = G (S_up (x) S_dn), see "Surface gates folded into a block")         [before the forward sweep]
 //   block_gradient    the block's angle gradients from the 4x4 environment
 //                         M_ij = sum_{other qubits, columns} conj(C_i) psi_j        [after the backward sweep]
 //                     where psi is the state before the block and C the loss cotangent after it:
@@ -119,14 +120,57 @@ CPF_HD void entangler_matrix(cx (&X)[4][4], int ent, float cc, float sc) {
     X[3][3] = mk(is_cx ? 0.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : sc);
 }
 
+// X <- E X (ADJ: E^+ X) on the rows, for the entangler `ent` with (cc, sc) = (cos a, sin a) of the CP angle
+template <bool ADJ>
+CPF_HD void entangler_rows(cx (&X)[4][4], int ent, float cc, float sc) {
+    const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;
+    const cx ph = mk(is_cx ? 1.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : (ADJ ? -sc : sc));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const cx r2 = X[2][j], r3 = X[3][j];
+        X[2][j] = is_cx ? r3 : r2;
+        X[3][j] = cmulc(ph, is_cx ? r2 : r3);
+    }
+}
+// Z <- Z E on the columns
+CPF_HD void entangler_cols(cx (&Z)[4][4], int ent, float cc, float sc) {
+    const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;
+    const cx ph = mk(is_cx ? 1.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : sc);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const cx c2 = Z[i][2], c3 = Z[i][3];
+        Z[i][2] = is_cx ? c3 : c2;
+        Z[i][3] = cmulc(ph, is_cx ? c2 : c3);
+    }
+}
+
+// Surface gates folded into a block.  The template starts with Rz(t2) Rx(t1) Rz(t0) on every qubit (main.py:122-124);
+// the first block that touches a qubit can carry that qubit's three rotations on its input side,
+//     G' = A_m ... A_1 E (S_up (x) S_dn),      S = Rz(t2) Rx(t1) Rz(t0)  or the identity,
+// so that the state sweeps never apply them: the forward sweep starts from the identity and the environment of the block
+// also yields the gradients of the folded angles (the walk below simply continues through E into the S factors).
+// `surf(side, k, &c, &s)`: (cos, sin) of the half angle of surface rotation k = 0, 1, 2 of the up (side 0) / dn (side 1) qubit.
+struct NoSurf { CPF_HD void operator()(int, int, float& c, float& s) const { c = 1.f; s = 0.f; } };
+CPF_HD int surf_kind(int k) { return k == 1 ? K_RX : K_RZ; }
+
 // rec: the block's gate records in program order, 4 floats each {cos, sin, code, -} with code = kind | q0 << 4 | q1 << 8
 // (the generic kernel's LDS records): rec[0] the entangler, then R_g(up), R_g(dn) per rotation letter.
 // `read(g, &c, &s, &kind)` abstracts the record fetch so that device code reads LDS and the CPU test reads an array.
-template <class Rec>
-CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot) {
+template <class Rec, class Surf = NoSurf>
+CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot, bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf()) {
     float c, s; int kind;
     rec(0, c, s, kind);
     entangler_matrix(G, kind, c, s);
+    if (fold_up || fold_dn) {                    // G = E S: start from the identity, S on the rows, then E
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) G[i][j] = mk(i == j ? 1.f : 0.f, 0.f);
+        float cs, ss;
+        if (fold_up) for (int k = 0; k < 3; k++) { surf(0, k, cs, ss); rot_rows<true>(G, surf_kind(k), cs, ss); }
+        if (fold_dn) for (int k = 0; k < 3; k++) { surf(1, k, cs, ss); rot_rows<false>(G, surf_kind(k), cs, ss); }
+        entangler_rows<false>(G, kind, c, s);
+    }
     for (int i = 0; i < n_rot; i++) {
         rec(1 + 2 * i, c, s, kind);
         rot_rows<true>(G, kind, c, s);
@@ -135,8 +179,10 @@ CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot) {
     }
 }
 // grad[0] = entangler angle (CP only, else 0), grad[1 + k] = rotation k in program order.  G = the block matrix.
-template <class Rec>
-CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot) {
+// gs_up[k] / gs_dn[k] (k = 0, 1, 2): gradients of the folded surface angles (written only for a folded side).
+template <class Rec, class Surf = NoSurf>
+CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot,
+                           bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf(), float* gs_up = nullptr, float* gs_dn = nullptr) {
     cx X[4][4], Z[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -154,8 +200,29 @@ CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4]
         rot_cols<true>(Z, kind, c, s);
     }
     rec(0, c, s, kind);
-    // dE/da = i |11><11| E  ->  dL/da = 2 Re(i (E Z)[3][3]) = -2 Im(e^{ia} Z[3][3])
-    grad[0] = kind == K_CP ? -2.f * (c * Z[3][3].im + s * Z[3][3].re) : 0.f;
+    // here X = E S and Z = M^T A_m .. A_1.  dE/da = i |11><11| E  ->  dL/da = 2 Re(i (X Z)[3][3]) = -2 Im (X Z)[3][3]
+    // (S = 1: X[3][j] = e^{ia} delta_j3, i.e. -2 Im(e^{ia} Z[3][3]))
+    float im33 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) im33 += X[3][j].re * Z[j][3].im + X[3][j].im * Z[j][3].re;
+    grad[0] = kind == K_CP ? -2.f * im33 : 0.f;
+    if (fold_up || fold_dn) {
+        entangler_rows<true>(X, kind, c, s);              // X = S
+        entangler_cols(Z, kind, c, s);                    // Z = M^T A_m .. A_1 E
+        float cs, ss;
+        if (fold_dn) for (int k = 2; k >= 0; k--) {
+            surf(1, k, cs, ss);
+            gs_dn[k] = im_trace_sigma<false>(X, Z, surf_kind(k));
+            rot_rows<false>(X, surf_kind(k), cs, -ss);
+            rot_cols<false>(Z, surf_kind(k), cs, ss);
+        }
+        if (fold_up) for (int k = 2; k >= 0; k--) {
+            surf(0, k, cs, ss);
+            gs_up[k] = im_trace_sigma<true>(X, Z, surf_kind(k));
+            rot_rows<true>(X, surf_kind(k), cs, -ss);
+            rot_cols<true>(Z, surf_kind(k), cs, ss);
+        }
+    }
 }
 
 // When the placement's first qubit sits on the LOWER of the two register bits the kernel applies the block with the

@@ -83,6 +83,7 @@ struct cpf_plan {
     std::vector<int> h_place;        // (up, dn) of every block
     std::vector<int> qperm;          // kernel qubit of problem qubit q
     std::map<int, DevBuf> dense_tab; // per waves-per-sample variant of the dense kernel: its per-block table (cpf_dense.h)
+    int dense_surf_mask[4] = {0, 0, 0, 0};   // ... and the qubits whose surface gates its sweeps still apply (not folded into a block)
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
     std::string variant;             // kernel variant of the last launch
@@ -332,6 +333,17 @@ int dense_table(cpf_plan* plan, DevBuf& tab) {
     // the same layer-aware rule as the layer-specialised kernels (cpf_dense.h dense_layer_entry): pair positions must agree
     const int LLn = (int)plan->layer_ud.size() / 2;
     for (int b = 0; b < K; b++) h[b] = cpf::dense_layer_entry<L>(plan->layer_ud.data(), LLn, b % LLn, 3 * plan->n + per_block * b);
+    // surface gates: folded into the first block that touches the qubit (cpf_dense_math.h); plan->dense_surf_mask keeps
+    // the qubits no block touches - their gates stay in the sweeps
+    int unfolded = (1 << plan->n) - 1;
+    const bool fold = !(tuning("CPF_DENSE_FOLD") && tuning("CPF_DENSE_FOLD")[0] == '0');
+    for (int b = 0; b < K; b++) {
+        const int up = plan->h_place[2 * b], dn = plan->h_place[2 * b + 1];
+        h[b].z |= (up << 12) | (dn << 16);
+        if (fold && ((unfolded >> up) & 1)) { h[b].z |= 512; unfolded &= ~(1 << up); }
+        if (fold && ((unfolded >> dn) & 1)) { h[b].z |= 1024; unfolded &= ~(1 << dn); }
+    }
+    plan->dense_surf_mask[L::LW] = unfolded;
     CPF_HIP(tab.alloc(h.size() * sizeof(cpf::DenseBlock)));
     CPF_HIP(hipMemcpy(tab.p, h.data(), h.size() * sizeof(cpf::DenseBlock), hipMemcpyHostToDevice));
     return 0;
@@ -347,7 +359,7 @@ bool dense_has_aot(int nq, int lw, const std::vector<int>& ud) {
 cpf_jit::Spec dense_jit_spec(int nq, int lw, const std::vector<int>& ud) {
     cpf_jit::Spec spec{"cpf_dense.h", cpf_jit::body_expr("dense_body", {nq, lw}, ud), 64 << lw};
     spec.arg = "cpf::DenseArgs";
-    spec.min_waves = (nq == 6 && lw == 1) ? 1 : 2;
+    spec.min_waves = 2;                       // layer-specialised sweeps fit 256 registers (two waves per SIMD)
     spec.flags = {CPF_DENSE_MLLVM_FLAGS};
     return spec;
 }
@@ -385,7 +397,7 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     const int wps = 1 << lw, threads = 64 << lw;
     const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, plan->K, nq, wps).total * sizeof(float);
     if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
-    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot};
+    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot, plan->dense_surf_mask[lw]};
     const bool specialised = dense_specialised(plan);
     // 1. run-time specialised (shipped cache / compile) unless an ahead-of-time instance of this very layer exists
     hipError_t e = hipSuccess;
@@ -632,7 +644,7 @@ const char* cpf_last_error(void) { return g_err; }
 
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW",
-                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_RELABEL", "CPF_FORCE_GENERIC",
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_RELABEL", "CPF_FORCE_GENERIC",
                                         "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)

@@ -18,3 +18,23 @@ extern "C" void dm_block_gradient(const float* rec, int n_rot, const float* G, c
     }
     block_gradient(grad, g, m, ArrRec{rec}, n_rot);
 }
+
+// with the surface gates of the up / dn qubit folded into the block: surf = [side][k]{cos, sin}
+struct ArrSurf {
+    const float* p;
+    void operator()(int side, int k, float& c, float& s) const { c = p[2 * (3 * side + k)]; s = p[2 * (3 * side + k) + 1]; }
+};
+extern "C" void dm_block_matrix_folded(const float* rec, int n_rot, int fold_up, int fold_dn, const float* surf, float* G) {
+    cx g[4][4];
+    block_matrix(g, ArrRec{rec}, n_rot, fold_up != 0, fold_dn != 0, ArrSurf{surf});
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = g[i][j].re; G[2 * (4 * i + j) + 1] = g[i][j].im; }
+}
+extern "C" void dm_block_gradient_folded(const float* rec, int n_rot, int fold_up, int fold_dn, const float* surf, const float* G, const float* M,
+                                         float* grad, float* gs_up, float* gs_dn) {
+    cx g[4][4], m[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        g[i][j] = mk(G[2 * (4 * i + j)], G[2 * (4 * i + j) + 1]);
+        m[i][j] = mk(M[2 * (4 * i + j)], M[2 * (4 * i + j) + 1]);
+    }
+    block_gradient(grad, g, m, ArrRec{rec}, n_rot, fold_up != 0, fold_dn != 0, ArrSurf{surf}, gs_up, gs_dn);
+}

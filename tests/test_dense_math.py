@@ -77,3 +77,56 @@ def test_block_matrix_and_gradient(shim, ent, kinds):
         if ent != K_CP:
             fd[0] = 0
         assert np.abs(grad - fd).max() < 2e-4 * max(1.0, np.abs(fd).max()), (grad, fd)
+
+
+@pytest.mark.parametrize('ent', [K_CP, K_CZ, K_CX])
+@pytest.mark.parametrize('fold', [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('kinds', [(K_RX, K_RY, K_RZ), (K_RX, K_RZ), ()])
+def test_block_with_folded_surface_gates(shim, ent, fold, kinds):
+    """The first block that touches a qubit carries that qubit's surface gate Rz(t2) Rx(t1) Rz(t0) (main.py:122-124) on
+    its input side: G' = G (S_up (x) S_dn).  Matrix against NumPy, all gradients (block angles and the folded surface
+    angles) against finite differences of L = 2 Re sum_ij G'_ij M_ij."""
+    rng = np.random.default_rng(11 * len(kinds) + 3 * ent + fold[0] + 2 * fold[1])
+    n_rot = len(kinds)
+
+    def full(angles, sa):
+        s_up = rot(K_RZ, sa[0, 2]) @ rot(K_RX, sa[0, 1]) @ rot(K_RZ, sa[0, 0]) if fold[0] else np.eye(2)
+        s_dn = rot(K_RZ, sa[1, 2]) @ rot(K_RX, sa[1, 1]) @ rot(K_RZ, sa[1, 0]) if fold[1] else np.eye(2)
+        return block(ent, kinds, angles) @ np.kron(s_up, s_dn)
+    for _ in range(4):
+        angles = rng.uniform(-4, 7, 1 + 2 * n_rot)
+        sa = rng.uniform(-4, 7, (2, 3))
+        rec = records(ent, kinds, angles)
+        surf = np.stack([np.cos(sa / 2), np.sin(sa / 2)], -1).astype(np.float32).reshape(-1)
+        G = np.zeros(32, np.float32)
+        shim.dm_block_matrix_folded(rec.ctypes.data_as(C.c_void_p), n_rot, fold[0], fold[1], surf.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p))
+        Gc = (G[0::2] + 1j * G[1::2]).reshape(4, 4)
+        assert np.abs(Gc - full(angles, sa)).max() < 3e-6
+        M = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+        Mf = np.stack([M.real, M.imag], -1).astype(np.float32).reshape(-1)
+        grad, gu, gd = np.zeros(1 + 2 * n_rot, np.float32), np.full(3, 7.0, np.float32), np.full(3, 7.0, np.float32)
+        shim.dm_block_gradient_folded(rec.ctypes.data_as(C.c_void_p), n_rot, fold[0], fold[1], surf.ctypes.data_as(C.c_void_p),
+                                      G.ctypes.data_as(C.c_void_p), Mf.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p),
+                                      gu.ctypes.data_as(C.c_void_p), gd.ctypes.data_as(C.c_void_p))
+        L = lambda a, q: 2 * np.real((full(a, q) * M).sum())  # noqa: E731
+        h = 1e-5
+        fd = np.zeros_like(angles)
+        for k in range(len(angles)):
+            ap, am = angles.copy(), angles.copy()
+            ap[k] += h
+            am[k] -= h
+            fd[k] = (L(ap, sa) - L(am, sa)) / (2 * h)
+        if ent != K_CP:
+            fd[0] = 0
+        scale = max(1.0, np.abs(fd).max())
+        assert np.abs(grad - fd).max() < 3e-4 * scale, (grad, fd)
+        for side, got in ((0, gu), (1, gd)):
+            if not fold[side]:
+                assert (got == 7.0).all()                  # an unfolded side is not written
+                continue
+            for k in range(3):
+                qp, qm = sa.copy(), sa.copy()
+                qp[side, k] += h
+                qm[side, k] -= h
+                want = (L(angles, qp) - L(angles, qm)) / (2 * h)
+                assert abs(got[k] - want) < 3e-4 * scale, (side, k, got, want)
