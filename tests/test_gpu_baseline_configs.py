@@ -131,12 +131,12 @@ def _ks_two_sample_p(a, b):
     return float(ks_2samp(a, b).pvalue)
 
 
-def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_tol, expect_variant=None, S_total=None):
+def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_tol, expect_variant=None, S_total=None, same_flag_min=0.95):
     """One BASELINE configuration at full length (S samples x 2000 iterations) on the kernel and on the float32 oracle
     (same initial angles, all host cores).  Individual runs are chaotic (lr 0.1 for 2000 steps), so the comparison is
     statistical: it would catch a systematic drift from fast_sincos, the rcp / sqrt Adam step, -fno-signed-zeros, a wrong
     gradient scale or a biased gradient of one kernel family, none of which a short-run test sees.  Bounds: pass count
-    within 3 sigma of a binomial with the pooled rate; >= 95 % of the samples get the same pass flag; CZ-count histograms
+    within 3 sigma of a binomial with the pooled rate; >= same_flag_min (95 %) of the samples get the same pass flag; CZ-count histograms
     of the converged samples compatible (two-sample chi-square below the 99.9 % quantile) and >= same_cz_min of the
     commonly converged samples with the same CZ count; quantiles of the best regularised loss over ALL samples within
     q_tol; median paired difference below pair_tol."""
@@ -154,7 +154,7 @@ def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_to
     sigma = np.sqrt(2 * S * p * (1 - p))                      # sd of the difference of two binomial counts
     print(f'[{wl.name} {variant}] passed: kernel {pg.sum()} oracle {po.sum()} (3 sigma = {3 * sigma:.1f}); same flag {np.mean(pg == po):.3f}')
     assert abs(int(pg.sum()) - int(po.sum())) <= max(3 * sigma, 1)
-    assert np.mean(pg == po) >= 0.95
+    assert np.mean(pg == po) >= same_flag_min
     both = pg & po
     if both.sum() >= 50:
         same_cz = np.mean(out['cz'][both] == ref['cz'][both])
@@ -205,7 +205,7 @@ def test_config4_unbiased_against_float32_oracle():
 
 def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
     """The 5-qubit benchmark problem of paper/results/benchmarks/res_4gt13_91 trial 99 (chain, 'xyz', 86 blocks, 617
-    angles, its stored target, seed and r): the first 256 of its 1000 samples over 2000 iterations on the relabelled
+    angles, its stored target, seed and r): all 1000 samples over 2000 iterations on the relabelled
     one-wave layered kernel from the shipped cache against the float32 oracle.  The stored run itself used older penalty
     constants, so it pins loss and initial angles only (tests/test_gpu_synthesis.py); this is the full-length pin of the
     5-qubit kernel."""
@@ -215,7 +215,11 @@ def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
     class Trial:
         name, layer, num_cp_gates, target, rotation_gates = '4gt13 trial 99', g['layer'].tolist(), int(g['num_cp_gates']), g['target'], str(g['rotation_gates'])
         r, seed, num_gd_iterations = float(g['r']), int(g['seed']), 2000
-    _unbiased_against_float32_oracle(Trial, 256, list(range(40, 80, 4)), 0.3, 2e-3, 2e-3, 'layered/jit(hipcc) waves=1', S_total=int(g['num_samples']))
+    # 86 blocks x 2000 steps on 5 qubits: which of the ~8 % of the runs end below entry_loss is decided by rounding (kernel and
+    # oracle agree on 89 % of the flags; independent draws at this rate would agree on 86 %), so the per-sample bars are low
+    # and the distribution-level ones carry the test
+    _unbiased_against_float32_oracle(Trial, int(g['num_samples']), list(range(40, 80, 4)), 0.0, 2e-3, 2e-3, 'layered/jit(hipcc) waves=1',
+                                     same_flag_min=0.8)
 
 
 @pytest.mark.parametrize('kernel', ['default', 'dense', 'gate-by-gate'])
