@@ -141,6 +141,13 @@ __device__ __forceinline__ f2 cmac_conj(f2 acc, f2 a, f2 b) { return pk_fma(f2{a
 // the two halves of a multiply-add separately, so that callers can advance several accumulators in lock step
 __device__ __forceinline__ f2 cmac_re(f2 acc, f2 a, f2 b) { return pk_fma(splat(a.x), b, acc); }
 __device__ __forceinline__ f2 cmac_im(f2 acc, f2 a, f2 b, bool conj) { return conj ? pk_fma(f2{a.y, -a.y}, swp(b), acc) : pk_fma(f2{-a.y, a.y}, swp(b), acc); }
+// acc + (a.y, -a.y) * (b.y, b.x): the imaginary half of acc += conj(a) b, as ONE instruction whatever the number of uses of a.
+// (Written in C++ the compiler keeps a multiply-used (a.y, a.y) pair in a register pair of its own: one v_mov_b32 per factor
+// and group, 32 per block in the environment accumulation, where every C_i meets four psi_j.)
+__device__ __forceinline__ f2 cmac_im_conj_asm(f2 acc, f2 a, f2 b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
 __device__ __forceinline__ f2 cmul0(f2 a, f2 b) { return pk_fma(f2{-a.y, a.y}, swp(b), splat(a.x) * b); }
 __device__ __forceinline__ f2 cmul0_conj(f2 a, f2 b) { return pk_fma(f2{a.y, -a.y}, swp(b), splat(a.x) * b); }
 
@@ -247,7 +254,7 @@ __device__ __forceinline__ void dense_backward(f2 (&p)[E], f2 (&c)[E], const f2 
 #pragma unroll
             for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_re(m[4 * i + j], cin[I0 + i], pq[j]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_im(m[4 * i + j], cin[I0 + i], pq[j], true);
+            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_im_conj_asm(m[4 * i + j], cin[I0 + i], pq[j]);
         }
         if constexpr (PART != 1) {
             f2 cq[4];

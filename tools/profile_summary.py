@@ -1,5 +1,6 @@
 """Turn the raw outputs of tools/profile.sh (gpurun_out/<tag>_<cfg>_*) into the committed summaries
-profiles/<tag>_<cfg>_kernel_stats.csv and profiles/<tag>_<cfg>_pmc_summary.json.    usage: profile_summary.py <tag> <cfg>"""
+profiles/<tag>_<cfg>_kernel_stats.csv and profiles/<tag>_<cfg>_pmc_summary.json.    usage: profile_summary.py <tag> <cfg> [--pmc-only]
+(--pmc-only: counter passes of tools/profile_pmc_only.sh, <cfg> = e.g. cfg2_S16384)"""
 import collections
 import csv
 import glob
@@ -18,25 +19,26 @@ def is_opt(name):
     return ('k_cp' in name or 'cpf_jit' in name) and 'initial' not in name and 'k_reg_rows' not in name
 
 
-bench = json.loads(open(os.path.join(out, f'{tag}_{cfg}_bench.json')).read().strip().splitlines()[-1])
-prof = json.loads(open(os.path.join(out, f'{tag}_{cfg}_bench_under_rocprof.json')).read().strip().splitlines()[-1])
-steps, warm = prof['steps'], prof['warmup']
-rows = [r for r in csv.DictReader(open(os.path.join(out, f'{tag}_{cfg}_kernel_trace.csv'))) if is_opt(r['Kernel_Name'])]
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
-timed = dur[warm:warm + steps]          # bench.py: warm-up launches, the timed launches, one more launch for the summary
-name = rows[warm]['Kernel_Name'].split('(')[0] if rows else ''
-os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
-with open(os.path.join(root, 'profiles', f'{tag}_{cfg}_kernel_stats.csv'), 'w', newline='') as f:
-    w = csv.writer(f)
-    w.writerow(['kernel', 'launches_all', 'launches_timed', 'mean_ms_timed', 'median_ms_timed', 'min_ms_timed', 'max_ms_timed', 'mean_ms_all',
-                'bench_kernel_ms_hip_events_under_rocprof', 'bench_kernel_ms_hip_events_unprofiled', 'VGPR', 'SGPR', 'LDS_bytes', 'workgroup', 'grid'])
-    r0 = rows[warm]
-    ev = lambda b: float(b['roofline']['note'].split('kernel ')[1].split(' ms')[0])  # noqa: E731
-    w.writerow([name, len(dur), len(timed), f'{statistics.mean(timed):.4f}', f'{statistics.median(timed):.4f}', f'{min(timed):.4f}', f'{max(timed):.4f}',
-                f'{statistics.mean(dur):.4f}', f'{ev(prof):.4f}', f'{ev(bench):.4f}', r0.get('VGPR_Count', ''), r0.get('SGPR_Count', ''),
-                r0.get('LDS_Block_Size', ''), r0.get('Workgroup_Size', r0.get('Workgroup_Size_X', '')), r0.get('Grid_Size', r0.get('Grid_Size_X', ''))])
-print(open(os.path.join(root, 'profiles', f'{tag}_{cfg}_kernel_stats.csv')).read())
+if '--pmc-only' not in sys.argv:
+    bench = json.loads(open(os.path.join(out, f'{tag}_{cfg}_bench.json')).read().strip().splitlines()[-1])
+    prof = json.loads(open(os.path.join(out, f'{tag}_{cfg}_bench_under_rocprof.json')).read().strip().splitlines()[-1])
+    steps, warm = prof['steps'], prof['warmup']
+    rows = [r for r in csv.DictReader(open(os.path.join(out, f'{tag}_{cfg}_kernel_trace.csv'))) if is_opt(r['Kernel_Name'])]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
+    timed = dur[warm:warm + steps]          # bench.py: warm-up launches, the timed launches, one more launch for the summary
+    name = rows[warm]['Kernel_Name'].split('(')[0] if rows else ''
+    os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
+    with open(os.path.join(root, 'profiles', f'{tag}_{cfg}_kernel_stats.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'launches_all', 'launches_timed', 'mean_ms_timed', 'median_ms_timed', 'min_ms_timed', 'max_ms_timed', 'mean_ms_all',
+                    'bench_kernel_ms_hip_events_under_rocprof', 'bench_kernel_ms_hip_events_unprofiled', 'VGPR', 'SGPR', 'LDS_bytes', 'workgroup', 'grid'])
+        r0 = rows[warm]
+        ev = lambda b: float(b['roofline']['note'].split('kernel ')[1].split(' ms')[0])  # noqa: E731
+        w.writerow([name, len(dur), len(timed), f'{statistics.mean(timed):.4f}', f'{statistics.median(timed):.4f}', f'{min(timed):.4f}', f'{max(timed):.4f}',
+                    f'{statistics.mean(dur):.4f}', f'{ev(prof):.4f}', f'{ev(bench):.4f}', r0.get('VGPR_Count', ''), r0.get('SGPR_Count', ''),
+                    r0.get('LDS_Block_Size', ''), r0.get('Workgroup_Size', r0.get('Workgroup_Size_X', '')), r0.get('Grid_Size', r0.get('Grid_Size_X', ''))])
+    print(open(os.path.join(root, 'profiles', f'{tag}_{cfg}_kernel_stats.csv')).read())
 
 # ---- counters: one optimise launch per pass (tools/gpu.py one <cfg>: warm-up launch + measured launch, both counted and averaged)
 tot, n, kern = collections.defaultdict(float), collections.defaultdict(int), set()
