@@ -33,6 +33,7 @@
 #pragma once
 #include "cpf_layered.h"
 #include "cpf_dense_math.h"
+#include "cpf_dense_asm.h"
 
 namespace cpf {
 
@@ -290,6 +291,76 @@ __device__ __forceinline__ void load_block_matrix(const float* gm, f2 (&g)[16]) 
     for (int i = 0; i < 8; i++) { const float4 v = gp[i]; g[2 * i] = f2{v.x, v.y}; g[2 * i + 1] = f2{v.z, v.w}; }
 }
 
+// ---- the block matrix in SCALAR registers -----------------------------------------------------------------------------
+// Read into vector registers the matrix costs every lane 32 register writes per block and pass (8 broadcast ds_read_b128:
+// 6.5 % of config 5's step, measured by leaving them out - not latency: fetching the next block's matrix early changed
+// nothing).  The matrix is uniform over the wave, so it belongs in scalar registers: the build phase also writes G to a global
+// scratch (DenseArgs::gmat, 128 B per block), the sweeps read it back with two s_load_dwordx16 - no vector-register traffic
+// at all - and every complex multiply-add takes its factor straight from a scalar register pair (cpf_dense_asm.h: one asm
+// statement of 32 instructions per group of four amplitudes; op_sel / neg on a scalar src0 measured in tools/micro/pk_sgpr.hip).
+// The scalar data cache does not see vector stores: it is invalidated once per step after the build phase (dense_body).
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef const volatile f16v __attribute__((address_space(4)))* gs_ptr;          // volatile: G changes every step, never hoist the read
+__device__ __forceinline__ void load_block_matrix_s(const float* gp, f2 (&g)[16]) {
+    gs_ptr p = reinterpret_cast<gs_ptr>((const __attribute__((address_space(4))) void*)gp);
+    const f16v lo = p[0], hi = p[1];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { g[k] = f2{lo[2 * k], lo[2 * k + 1]}; g[8 + k] = f2{hi[2 * k], hi[2 * k + 1]}; }
+}
+// Scalar loads return out of order, so every wait on them is s_waitcnt lgkmcnt(0): to have the NEXT block's matrix in flight
+// under the current block's arithmetic its loads must be issued after the wait for the current one.  dense_touch_s makes the
+// compiler place that wait here (an empty statement that reads all sixteen pairs), the caller issues the next loads after it.
+__device__ __forceinline__ void dense_touch_s(const f2 (&g)[16]) {
+    asm volatile("" :: "s"(g[0]), "s"(g[1]), "s"(g[2]), "s"(g[3]), "s"(g[4]), "s"(g[5]), "s"(g[6]), "s"(g[7]),
+                       "s"(g[8]), "s"(g[9]), "s"(g[10]), "s"(g[11]), "s"(g[12]), "s"(g[13]), "s"(g[14]), "s"(g[15]));
+}
+template <int E, int RA, int RB, bool ADJ>
+__device__ __forceinline__ void dense_apply_s(f2 (&x)[E], const f2 (&g)[16]) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (e & ((1 << RA) | (1 << RB))) continue;
+        const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
+        f2 o0, o1, o2, o3;
+        if constexpr (ADJ) dense_group_adj_s(o0, o1, o2, o3, x[idx[0]], x[idx[1]], x[idx[2]], x[idx[3]], g);
+        else dense_group_fwd_s(o0, o1, o2, o3, x[idx[0]], x[idx[1]], x[idx[2]], x[idx[3]], g);
+        x[idx[0]] = o0; x[idx[1]] = o1; x[idx[2]] = o2; x[idx[3]] = o3;
+    }
+}
+// the backward pass of one block with the matrix in scalar registers (same parts as dense_backward)
+template <int E, int RA, int RB, int PART>
+__device__ __forceinline__ void dense_backward_s(f2 (&p)[E], f2 (&c)[E], const f2 (&g)[16], f2 (&m)[PART == 0 ? 16 : 8]) {
+    constexpr int I0 = PART == 2 ? 2 : 0, NI = PART == 0 ? 4 : 2;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (e & ((1 << RA) | (1 << RB))) continue;
+        const int idx[4] = {e, e | (1 << RA), e | (1 << RB), e | (1 << RA) | (1 << RB)};
+        const f2 cin[4] = {c[idx[0]], c[idx[1]], c[idx[2]], c[idx[3]]};
+        f2 pq[4];
+        if constexpr (PART != 2) {
+            dense_group_adj_s(pq[0], pq[1], pq[2], pq[3], p[idx[0]], p[idx[1]], p[idx[2]], p[idx[3]], g);
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[idx[i]] = pq[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pq[i] = p[idx[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[4 * i + j] = e == 0 ? splat(cin[I0 + i].x) * pq[j] : cmac_re(m[4 * i + j], cin[I0 + i], pq[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[4 * i + j] = cmac_im_conj_asm(m[4 * i + j], cin[I0 + i], pq[j]);
+        }
+        if constexpr (PART != 1) {
+            f2 cq[4];
+            dense_group_adj_s(cq[0], cq[1], cq[2], cq[3], cin[0], cin[1], cin[2], cin[3], g);
+#pragma unroll
+            for (int i = 0; i < 4; i++) c[idx[i]] = cq[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 #define CPF_PAIR_SWITCH(PAIR, BODY)                                                                   \
     switch (PAIR) {                                                                                   \
         case 0x10: { constexpr int RA = 0, RB = 1; BODY; } break;                                     \
@@ -453,7 +524,11 @@ struct DenseLds {
 // surf_mask: qubits whose surface gate Rz Rx Rz the sweeps apply gate by gate; every other qubit's surface gate is folded
 // into the first block that touches it (cpf_dense_math.h; DenseBlock::z bits 9 / 10), which removes 3 x 18 rotations of
 // the full state per step (config 5: 6.4 % of the step, measured by leaving them out)
-struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot, surf_mask; };
+// gmat: global scratch [samples][K][32 floats] for the block matrices of the scalar-register path (layer-specialised kernels)
+struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot, surf_mask; float* gmat; };
+#ifndef CPF_DENSE_SGPR
+#define CPF_DENSE_SGPR 1
+#endif
 
 // UD... = the layer as (up, dn) pairs (block b sits on pair b mod length): the block loops are then straight-line code per
 // layer with compile-time register bits and exchanges.  Empty UD: any circuit, every block dispatched through the table.
@@ -463,6 +538,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
     using PL = PairList<UD...>;
     constexpr int LL = sizeof...(UD) / 2;
     constexpr bool HALVES = L::E >= 32;                  // environment accumulated in two halves (register budget)
+    constexpr bool SG = LL > 0 && CPF_DENSE_SGPR != 0;   // block matrices in scalar registers (layer-specialised sweeps)
     constexpr int E = L::E, WPS = L::WPS, THREADS = L::THREADS, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
     const KArgs& a = da.k;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -547,6 +623,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             dense::block_matrix(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
             const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
             float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
+            float2* gout = SG ? reinterpret_cast<float2*>(da.gmat + ((size_t)s_idx * K + b) * 32) : nullptr;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -554,9 +631,16 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                     const dense::cx v = Gb[i][j];
                     const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
                     out[4 * ii + jj] = make_float2(v.re, v.im);
+                    if constexpr (SG) gout[4 * ii + jj] = make_float2(v.re, v.im);
                 }
         }
+        if constexpr (SG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the matrices have reached L2 ...
         lds_sync<WPS>();
+        if constexpr (SG) {                                                        // ... and no stale line of theirs stays in the scalar cache
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const float* gsample = SG ? da.gmat + (size_t)s_idx * K * 32 : nullptr;
 
         // ================= forward
 #pragma unroll
@@ -592,6 +676,31 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             // cost 6.5 % of config 5's step).
             auto fwd_layer = [&](auto tail) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail)::value != 0;        // the truncated last layer: blocks while b < K
+                if constexpr (SG) {
+                    f2 sa[16], sb[16];                               // scalar pairs: this block's matrix and the next one's
+                    if (!TAIL || b < K) load_block_matrix_s(gsample + 32 * b, sa);
+                    static_for([&](auto jj) __attribute__((always_inline)) {
+                        constexpr int J = decltype(jj)::value;
+                        constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
+                        constexpr int RA = ent.z & 15, RB = (ent.z >> 4) & 15;
+                        constexpr bool KEPT = dense_same_swap<L>(PL::v, LL, J - 1, J), KEEP = dense_same_swap<L>(PL::v, LL, J, J + 1);
+                        if (TAIL && b >= K) return;
+                        auto body = [&](f2 (&g)[16], f2 (&gnext)[16]) __attribute__((always_inline)) {
+                            dense_touch_s(g);
+                            if constexpr (J + 1 < LL) { if (!TAIL || b + 1 < K) load_block_matrix_s(gsample + 32 * (b + 1), gnext); }
+                            if constexpr (ent.x >= 0 && !KEPT) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                            if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                            dense_apply_s<E, RA, RB, false>(psi, g);
+                            if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
+                            if constexpr (ent.x >= 0) {
+                                if (!KEEP || b + 1 >= K) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
+                            }
+                            b++;
+                        };
+                        if constexpr (J & 1) body(sb, sa); else body(sa, sb);
+                    }, typename make_iseq<LL>::type{});
+                    return;
+                }
                 f2 ga[16], gb[16];
                 if (!TAIL || b < K) load_block_matrix(smem + lds.gm + 32 * b, ga);
                 static_for([&](auto jj) __attribute__((always_inline)) {
@@ -685,7 +794,17 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         // next block's matrix into the same registers there, under the environment reduction and the exchanges that follow.
         auto bwd_block = [&](auto ra, auto rb, f2 (&g)[16], int b, auto&& prefetch) __attribute__((always_inline)) {
             constexpr int RA = decltype(ra)::value, RB = decltype(rb)::value;
-            if constexpr (HALVES) {
+            if constexpr (SG && HALVES) {
+                f2 m[8];
+                dense_backward_s<E, RA, RB, 1>(psi, cot, g, m);
+                dense_env_reduce16(m, env_w + 32 * b, env_dst);
+                dense_backward_s<E, RA, RB, 2>(psi, cot, g, m);
+                dense_env_reduce16(m, env_w + 32 * b + 16, env_dst);
+            } else if constexpr (SG) {
+                f2 m[16];
+                dense_backward_s<E, RA, RB, 0>(psi, cot, g, m);
+                dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+            } else if constexpr (HALVES) {
                 f2 m[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) m[i] = f2{0.f, 0.f};
@@ -722,11 +841,20 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             auto bwd_layer = [&](auto tail) __attribute__((always_inline)) {
                 constexpr bool TAIL = decltype(tail)::value != 0;
                 const int tail_len = K % LL;
-                f2 g[16];
-                load_block_matrix(smem + lds.gm + 32 * b, g);            // the layer's first matrix: the only exposed read of the layer
+                f2 g[16], g2[16];                                    // g2: the scalar-register path's second buffer
+                if constexpr (!SG) load_block_matrix(smem + lds.gm + 32 * b, g);        // the layer's first matrix: the only exposed read of the layer
+                bool first = true;
                 static_for([&](auto jj) __attribute__((always_inline)) {
                     constexpr int J = LL - 1 - decltype(jj)::value;
                     if (TAIL && J >= tail_len) return;
+                    if constexpr (SG) {
+                        // blocks J = LL - 1 ... 0 alternate between the buffers; the first one swept (LL - 1, or tail_len - 1) loads its own
+                        f2 (&gc)[16] = (J & 1) ? g2 : g;
+                        f2 (&gn)[16] = (J & 1) ? g : g2;
+                        if (first) { load_block_matrix_s(gsample + 32 * b, gc); first = false; }
+                        dense_touch_s(gc);
+                        if constexpr (J > 0) load_block_matrix_s(gsample + 32 * (b - 1), gn);
+                    }
                     constexpr DenseBlock ent = dense_layer_entry<L>(PL::v, LL, J, 0);
                     // mirror image of the forward sweep: block J + 1 (swept just before) leaves the exchange in place unless it
                     // was the last block of the circuit's own (b + 1 == K: nothing was swept before this block)
@@ -735,8 +863,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                         if (!KEPT || b + 1 >= K) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
                     }
                     if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
-                    bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, g, b, [&](f2 (&gg)[16]) __attribute__((always_inline)) {
-                        if constexpr (J > 0) {
+                    bwd_block(ic<(ent.z & 15)>{}, ic<((ent.z >> 4) & 15)>{}, (SG && (J & 1)) ? g2 : g, b, [&](f2 (&gg)[16]) __attribute__((always_inline)) {
+                        if constexpr (J > 0 && !SG) {
                             load_block_matrix(smem + lds.gm + 32 * (b - 1), gg);
                             __builtin_amdgcn_sched_barrier(0);           // the reads stay here (the scheduler would sink them to their first use)
                         }

@@ -83,6 +83,8 @@ struct cpf_plan {
     std::vector<int> h_place;        // (up, dn) of every block
     std::vector<int> qperm;          // kernel qubit of problem qubit q
     std::map<int, DevBuf> dense_tab; // per waves-per-sample variant of the dense kernel: its per-block table (cpf_dense.h)
+    DevBuf dense_gmat;               // [samples][K][32] floats: block matrices for the dense kernel's scalar loads (cpf_dense.h)
+    size_t dense_gmat_bytes = 0;
     int dense_surf_mask[4] = {0, 0, 0, 0};   // ... and the qubits whose surface gates its sweeps still apply (not folded into a block)
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
@@ -397,7 +399,15 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     const int wps = 1 << lw, threads = 64 << lw;
     const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, plan->K, nq, wps).total * sizeof(float);
     if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
-    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot, plan->dense_surf_mask[lw]};
+    // global scratch of the scalar-register path: one 128-byte matrix per block and sample, rebuilt every step by the kernel
+    const size_t gbytes = (size_t)S * (size_t)plan->K * 32 * sizeof(float);
+    if (gbytes > plan->dense_gmat_bytes) {
+        CPF_HIP(hipStreamSynchronize(stream));
+        if (plan->dense_gmat.p) { (void)hipFree(plan->dense_gmat.p); plan->dense_gmat.p = nullptr; }
+        CPF_HIP(plan->dense_gmat.alloc(gbytes));
+        plan->dense_gmat_bytes = gbytes;
+    }
+    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot, plan->dense_surf_mask[lw], plan->dense_gmat.as<float>()};
     const bool specialised = dense_specialised(plan);
     // 1. run-time specialised (shipped cache / compile) unless an ahead-of-time instance of this very layer exists
     hipError_t e = hipSuccess;
