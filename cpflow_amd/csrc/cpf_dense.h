@@ -357,7 +357,6 @@ __device__ __forceinline__ void dense_backward_s(f2 (&p)[E], f2 (&c)[E], const f
 #pragma unroll
             for (int i = 0; i < 4; i++) c[idx[i]] = cq[i];
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
