@@ -466,26 +466,32 @@ __device__ __forceinline__ void dense_env_reduce(const f2 (&m)[16], float* dst, 
     dst[dst_lane] = r;
 }
 
-// 16 values (8 complex accumulators, one half of the environment): value v summed over the wave, left in dst[v]
+// 16 values (8 complex accumulators, one half of the environment; value 2 k + c = component c of m[k]): value v summed over
+// the wave, left in dst[v].  Lane bits 5 and 4 by permlane swaps of the SAME component of two neighbouring accumulators, so
+// that one v_pk_add_f32 settles four values (2 swaps + 1 add per 4 values), then the 4-value DPP reduce-scatter over bits 2, 3
+// and plain sums over bits 0, 1.  After the two permlane stages register pair r holds accumulator k = 4 r + 2 (bit 4) + (bit 5).
 __device__ __forceinline__ int dense_env_dst16(int lane) {
-    return 4 * (2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+    return 8 * ((lane >> 3) & 1) + 4 * ((lane >> 4) & 1) + 2 * ((lane >> 5) & 1) + ((lane >> 2) & 1);
 }
 __device__ __forceinline__ void dense_env_reduce16(const f2 (&m)[8], float* dst, int dst_lane) {
 #ifdef CPF_EXP_NOREDUCE           // timing experiment only (wrong results): one add tree per lane, no cross-lane traffic
     dst[dst_lane] = ((m[0].x + m[1].y) + (m[2].x + m[3].y)) + ((m[4].x + m[5].y) + (m[6].x + m[7].y));
     return;
 #endif
-    float w[8], u[4];
+    f2 w[4], u2[2];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {                        // bit 5: values 2r (low half), 2r + 1 (high half); m[r] = (v[2r], v[2r + 1])
-        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[r].x), __float_as_uint(m[r].y), false, false);
-        w[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    for (int r = 0; r < 4; r++) {                        // bit 5: accumulators 2r (kept by the low half), 2r + 1 (high half)
+        const auto tx = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[2 * r].x), __float_as_uint(m[2 * r + 1].x), false, false);
+        const auto ty = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[2 * r].y), __float_as_uint(m[2 * r + 1].y), false, false);
+        w[r] = f2{__uint_as_float(tx[0]), __uint_as_float(ty[0])} + f2{__uint_as_float(tx[1]), __uint_as_float(ty[1])};
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {                        // bit 4
-        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r]), __float_as_uint(w[2 * r + 1]), false, false);
-        u[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    for (int r = 0; r < 2; r++) {                        // bit 4
+        const auto tx = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r].x), __float_as_uint(w[2 * r + 1].x), false, false);
+        const auto ty = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r].y), __float_as_uint(w[2 * r + 1].y), false, false);
+        u2[r] = f2{__uint_as_float(tx[0]), __uint_as_float(ty[0])} + f2{__uint_as_float(tx[1]), __uint_as_float(ty[1])};
     }
+    const float u[4] = {u2[0].x, u2[0].y, u2[1].x, u2[1].y};
     float e0, e1, f0;                                    // bits 2, 3: reduce-scatter 4 -> 1 under bank masks (cpf_blocks.h)
     asm("s_nop 1\n\t"
         "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
