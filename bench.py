@@ -161,7 +161,7 @@ def stored_traffic(config, samples_per_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)      # 0.6 s of back-to-back launches at config 2: long enough for a utilisation sampler
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help='BASELINE.json configuration (default: configs[1], the one the metric is quoted on)')

@@ -625,7 +625,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         for (int b = tid; b < K; b += THREADS) {
             const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
             dense::cx Gb[4][4];
+#ifdef CPF_EXP_NOBUILD            // timing experiment only (wrong results)
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Gb[i][j] = dense::mk(i == j ? 1.f : 0.f, th[b] * 1e-9f);
+#else
             dense::block_matrix(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
+#endif
             const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
             float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
             float2* gout = SG ? reinterpret_cast<float2*>(da.gmat + ((size_t)s_idx * K + b) * 32) : nullptr;
@@ -635,8 +639,8 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                 for (int j = 0; j < 4; j++) {
                     const dense::cx v = Gb[i][j];
                     const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
-                    out[4 * ii + jj] = make_float2(v.re, v.im);
-                    if constexpr (SG) gout[4 * ii + jj] = make_float2(v.re, v.im);
+                    out[4 * ii + jj] = make_float2(dense::re(v), dense::im(v));
+                    if constexpr (SG) gout[4 * ii + jj] = make_float2(dense::re(v), dense::im(v));
                 }
         }
         if constexpr (SG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the matrices have reached L2 ...
@@ -931,7 +935,11 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                 }
             const int qu = (z >> 12) & 15, qd = (z >> 16) & 15;
             // gate g0 + i carries angle i of the block; a folded surface gate's angles are gates 3 q .. 3 q + 2
+#ifdef CPF_EXP_NOCHAIN            // timing experiment only (wrong results)
+            gw[g0] = dense::re(Mb[0][0]) + dense::im(Gb[1][1]);
+#else
             dense::block_gradient(gw + g0, Gb, Mb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec(qu, qd), gw + 3 * qu, gw + 3 * qd);
+#endif
         }
         for (int g = tid; g < NS; g += THREADS) {
             if (!((da.surf_mask >> (g / 3)) & 1)) continue;              // written by the block the gate is folded into

@@ -25,9 +25,37 @@ namespace dense {
 
 enum : int { K_RX = 0, K_RY = 1, K_RZ = 2, K_CP = 3, K_CZ = 4, K_CX = 5 };     // = OP_* of cpf_device.h
 
+// A complex number.  On the device it is a two-float vector, so that every helper below is one or two packed instructions
+// (v_pk_mul_f32 / v_pk_fma_f32): the per-block walks run on one thread per block while the other lanes wait, so their
+// instruction count is serial time (config 5: the gradient walk cost 5 % of the step with scalar arithmetic).  On the CPU
+// (tests/dense_math_shim.cpp) the same helpers are plain float code.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float cxv __attribute__((ext_vector_type(2)));
+struct cx { cxv v; };
+CPF_HD cx mk(float re, float im) { cx r; r.v = cxv{re, im}; return r; }
+CPF_HD float re(cx a) { return a.v.x; }
+CPF_HD float im(cx a) { return a.v.y; }
+CPF_HD cx cmulc(cx a, cx b) { cx r; r.v = __builtin_elementwise_fma(cxv{-a.v.y, a.v.y}, cxv{b.v.y, b.v.x}, cxv{a.v.x, a.v.x} * b.v); return r; }
+// (c a.re + p b.im,  c a.im + q b.re)
+CPF_HD cx lin_swap(float c, cx a, float p, float q, cx b) { cx r; r.v = __builtin_elementwise_fma(cxv{p, q}, cxv{b.v.y, b.v.x}, cxv{c, c} * a.v); return r; }
+// c a + s b
+CPF_HD cx lin(float c, cx a, float s, cx b) { cx r; r.v = __builtin_elementwise_fma(cxv{s, s}, b.v, cxv{c, c} * a.v); return r; }
+// accumulators of sum x z: acc_swap collects (x.re z.im, x.im z.re), acc_same (x.re z.re, x.im z.im); NEG subtracts the term
+template <bool NEG> CPF_HD cx acc_swap(cx acc, cx x, cx z) { cx r; r.v = __builtin_elementwise_fma(NEG ? -x.v : x.v, cxv{z.v.y, z.v.x}, acc.v); return r; }
+template <bool NEG> CPF_HD cx acc_same(cx acc, cx x, cx z) { cx r; r.v = __builtin_elementwise_fma(NEG ? -x.v : x.v, z.v, acc.v); return r; }
+CPF_HD cx sel(bool t, cx a, cx b) { cx r; r.v = cxv{t ? a.v.x : b.v.x, t ? a.v.y : b.v.y}; return r; }
+#else
 struct cx { float re, im; };
 CPF_HD cx mk(float re, float im) { cx r; r.re = re; r.im = im; return r; }
+CPF_HD float re(cx a) { return a.re; }
+CPF_HD float im(cx a) { return a.im; }
 CPF_HD cx cmulc(cx a, cx b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+CPF_HD cx lin_swap(float c, cx a, float p, float q, cx b) { return mk(c * a.re + p * b.im, c * a.im + q * b.re); }
+CPF_HD cx lin(float c, cx a, float s, cx b) { return mk(c * a.re + s * b.re, c * a.im + s * b.im); }
+template <bool NEG> CPF_HD cx acc_swap(cx acc, cx x, cx z) { return NEG ? mk(acc.re - x.re * z.im, acc.im - x.im * z.re) : mk(acc.re + x.re * z.im, acc.im + x.im * z.re); }
+template <bool NEG> CPF_HD cx acc_same(cx acc, cx x, cx z) { return NEG ? mk(acc.re - x.re * z.re, acc.im - x.im * z.im) : mk(acc.re + x.re * z.re, acc.im + x.im * z.im); }
+CPF_HD cx sel(bool t, cx a, cx b) { return t ? a : b; }
+#endif
 
 // X <- R X (rows) for R = exp(-i a sigma / 2) on the up (bit 1) or dn (bit 0) index; (c, s) = (cos a/2, sin a/2);
 // s -> -s gives the inverse.  X[r][j], r = 2 up + dn.
@@ -42,14 +70,14 @@ CPF_HD void rot_rows(cx (&X)[4][4], int kind, float c, float s) {
         for (int j = 0; j < 4; j++) {
             const cx x0 = X[r0][j], x1 = X[r1][j];
             if (kind == K_RX) {            // [[c, -is], [-is, c]]
-                X[r0][j] = mk(c * x0.re + s * x1.im, c * x0.im - s * x1.re);
-                X[r1][j] = mk(c * x1.re + s * x0.im, c * x1.im - s * x0.re);
+                X[r0][j] = lin_swap(c, x0, s, -s, x1);
+                X[r1][j] = lin_swap(c, x1, s, -s, x0);
             } else if (kind == K_RY) {     // [[c, -s], [s, c]]
-                X[r0][j] = mk(c * x0.re - s * x1.re, c * x0.im - s * x1.im);
-                X[r1][j] = mk(c * x1.re + s * x0.re, c * x1.im + s * x0.im);
+                X[r0][j] = lin(c, x0, -s, x1);
+                X[r1][j] = lin(c, x1, s, x0);
             } else {                       // diag(c - is, c + is)
-                X[r0][j] = mk(c * x0.re + s * x0.im, c * x0.im - s * x0.re);
-                X[r1][j] = mk(c * x1.re - s * x1.im, c * x1.im + s * x1.re);
+                X[r0][j] = lin_swap(c, x0, s, -s, x0);
+                X[r1][j] = lin_swap(c, x1, -s, s, x1);
             }
         }
     }
@@ -66,14 +94,14 @@ CPF_HD void rot_cols(cx (&Z)[4][4], int kind, float c, float s) {
         for (int i = 0; i < 4; i++) {
             const cx z0 = Z[i][c0], z1 = Z[i][c1];
             if (kind == K_RX) {            // (Z R)[i][c0] = c z0 - i s z1, [i][c1] = -i s z0 + c z1
-                Z[i][c0] = mk(c * z0.re + s * z1.im, c * z0.im - s * z1.re);
-                Z[i][c1] = mk(c * z1.re + s * z0.im, c * z1.im - s * z0.re);
+                Z[i][c0] = lin_swap(c, z0, s, -s, z1);
+                Z[i][c1] = lin_swap(c, z1, s, -s, z0);
             } else if (kind == K_RY) {     // [i][c0] = c z0 + s z1, [i][c1] = -s z0 + c z1
-                Z[i][c0] = mk(c * z0.re + s * z1.re, c * z0.im + s * z1.im);
-                Z[i][c1] = mk(c * z1.re - s * z0.re, c * z1.im - s * z0.im);
+                Z[i][c0] = lin(c, z0, s, z1);
+                Z[i][c1] = lin(c, z1, -s, z0);
             } else {
-                Z[i][c0] = mk(c * z0.re + s * z0.im, c * z0.im - s * z0.re);
-                Z[i][c1] = mk(c * z1.re - s * z1.im, c * z1.im + s * z1.re);
+                Z[i][c0] = lin_swap(c, z0, s, -s, z0);
+                Z[i][c1] = lin_swap(c, z1, -s, s, z1);
             }
         }
     }
@@ -82,28 +110,26 @@ CPF_HD void rot_cols(cx (&Z)[4][4], int kind, float c, float s) {
 template <bool ON_UP>
 CPF_HD float im_trace_sigma(const cx (&X)[4][4], const cx (&Z)[4][4], int kind) {
     constexpr int b = ON_UP ? 2 : 1;
-    float acc = 0.f;
+    // four accumulators (one per row r) advance in turn: a packed multiply-add that reads the result of the instruction
+    // right before it is padded with an s_nop on this chip
+    cx a4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const bool hi = (r & b) != 0;
+    for (int j = 0; j < 4; j++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int r = 0; r < 4; r++) {
+            const bool hi = (r & b) != 0;
             const cx z = Z[j][r];
-            if (kind == K_RX) {            // (sigma X)[r] = X[r ^ b]
-                const cx x = X[r ^ b][j];
-                acc += x.re * z.im + x.im * z.re;
-            } else if (kind == K_RY) {     // (sigma X)[r] = -i X[r ^ b] (bit clear), +i X[r ^ b] (bit set)
-                const cx x = X[r ^ b][j];
-                const float im = x.re * z.re - x.im * z.im;      // Im(i x z) = Re(x z)
-                acc += hi ? im : -im;
+            if (kind == K_RX) {            // (sigma X)[r] = X[r ^ b]:  Im(x z) = x.re z.im + x.im z.re
+                a4[r] = acc_swap<false>(a4[r], X[r ^ b][j], z);
+            } else if (kind == K_RY) {     // (sigma X)[r] = -i X[r ^ b] (bit clear), +i X[r ^ b] (bit set):  Im(+-i x z) = +-Re(x z)
+                a4[r] = hi ? acc_same<false>(a4[r], X[r ^ b][j], z) : acc_same<true>(a4[r], X[r ^ b][j], z);
             } else {                       // (sigma X)[r] = +X[r] (bit clear), -X[r] (bit set)
-                const cx x = X[r][j];
-                const float im = x.re * z.im + x.im * z.re;
-                acc += hi ? -im : im;
+                a4[r] = hi ? acc_swap<true>(a4[r], X[r][j], z) : acc_swap<false>(a4[r], X[r][j], z);
             }
         }
     }
-    return acc;
+    const cx acc = mk((re(a4[0]) + re(a4[1])) + (re(a4[2]) + re(a4[3])), (im(a4[0]) + im(a4[1])) + (im(a4[2]) + im(a4[3])));
+    return kind == K_RY ? re(acc) - im(acc) : re(acc) + im(acc);      // Re(x z) = x.re z.re - x.im z.im
 }
 
 // Entangler as the starting matrix.  (cc, sc) = (cos a, sin a) of the CP angle (unused for CZ / CX).
@@ -128,8 +154,8 @@ CPF_HD void entangler_rows(cx (&X)[4][4], int ent, float cc, float sc) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const cx r2 = X[2][j], r3 = X[3][j];
-        X[2][j] = is_cx ? r3 : r2;
-        X[3][j] = cmulc(ph, is_cx ? r2 : r3);
+        X[2][j] = sel(is_cx, r3, r2);
+        X[3][j] = cmulc(ph, sel(is_cx, r2, r3));
     }
 }
 // Z <- Z E on the columns
@@ -139,8 +165,8 @@ CPF_HD void entangler_cols(cx (&Z)[4][4], int ent, float cc, float sc) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const cx c2 = Z[i][2], c3 = Z[i][3];
-        Z[i][2] = is_cx ? c3 : c2;
-        Z[i][3] = cmulc(ph, is_cx ? c2 : c3);
+        Z[i][2] = sel(is_cx, c3, c2);
+        Z[i][3] = cmulc(ph, sel(is_cx, c2, c3));
     }
 }
 
@@ -202,10 +228,10 @@ CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4]
     rec(0, c, s, kind);
     // here X = E S and Z = M^T A_m .. A_1.  dE/da = i |11><11| E  ->  dL/da = 2 Re(i (X Z)[3][3]) = -2 Im (X Z)[3][3]
     // (S = 1: X[3][j] = e^{ia} delta_j3, i.e. -2 Im(e^{ia} Z[3][3]))
-    float im33 = 0.f;
+    cx a33 = mk(0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 4; j++) im33 += X[3][j].re * Z[j][3].im + X[3][j].im * Z[j][3].re;
-    grad[0] = kind == K_CP ? -2.f * im33 : 0.f;
+    for (int j = 0; j < 4; j++) a33 = acc_swap<false>(a33, X[3][j], Z[j][3]);
+    grad[0] = kind == K_CP ? -2.f * (re(a33) + im(a33)) : 0.f;
     if (fold_up || fold_dn) {
         entangler_rows<true>(X, kind, c, s);              // X = S
         entangler_cols(Z, kind, c, s);                    // Z = M^T A_m .. A_1 E

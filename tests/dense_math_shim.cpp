@@ -8,7 +8,7 @@ struct ArrRec {
 extern "C" void dm_block_matrix(const float* rec, int n_rot, float* G) {
     cx g[4][4];
     block_matrix(g, ArrRec{rec}, n_rot);
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = g[i][j].re; G[2 * (4 * i + j) + 1] = g[i][j].im; }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = re(g[i][j]); G[2 * (4 * i + j) + 1] = im(g[i][j]); }
 }
 extern "C" void dm_block_gradient(const float* rec, int n_rot, const float* G, const float* M, float* grad) {
     cx g[4][4], m[4][4];
@@ -27,7 +27,7 @@ struct ArrSurf {
 extern "C" void dm_block_matrix_folded(const float* rec, int n_rot, int fold_up, int fold_dn, const float* surf, float* G) {
     cx g[4][4];
     block_matrix(g, ArrRec{rec}, n_rot, fold_up != 0, fold_dn != 0, ArrSurf{surf});
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = g[i][j].re; G[2 * (4 * i + j) + 1] = g[i][j].im; }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = re(g[i][j]); G[2 * (4 * i + j) + 1] = im(g[i][j]); }
 }
 extern "C" void dm_block_gradient_folded(const float* rec, int n_rot, int fold_up, int fold_dn, const float* surf, const float* G, const float* M,
                                          float* grad, float* gs_up, float* gs_dn) {

@@ -8,7 +8,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = '''
 import sys; sys.path.insert(0, %r)
-from cpflow_amd import workloads
+from cpflow_amd import workloads, _ffi
+import ctypes
+_h = ctypes.CDLL(_ffi.LIB_PATH)
+for _k in list(_ffi.SYMBOLS):
+    if not hasattr(_h, _k): _ffi.SYMBOLS.pop(_k)          # an older build (A/B reference) may lack newer entry points
 from cpflow_amd.engine import TemplateEngine
 import torch
 wl = workloads.CONFIGS[sys.argv[1]]
