@@ -601,7 +601,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
     auto block_rec = [&](int g0) {
         return [rec, g0](int i, float& c, float& s, int& kind) {
             const float4 r = rec[g0 + i];
-            c = r.x; s = r.y; kind = __float_as_int(r.z) & 15;
+            // gate i of every block has the same kind (one rotation string, one entangler per template): a scalar, so that
+            // the three-way choice in the 4x4 helpers is a scalar branch and not three masked passes
+            c = r.x; s = r.y; kind = __builtin_amdgcn_readfirstlane(__float_as_int(r.z) & 15);
         };
     };
 
