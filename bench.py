@@ -243,17 +243,7 @@ def main():
 
     # what torch.distributed saw: backend, world size, and the distinct devices behind the ranks (every rank contributes
     # its device's UUID / PCI bus id), so that a reader can tell N ranks on N devices from N ranks on one
-    props = torch.cuda.get_device_properties(eng.device)
-    me = {'rank': rank, 'device_index': eng.device.index, 'uuid': str(getattr(props, 'uuid', '')),
-          'pci_bus_id': f'{getattr(props, "pci_domain_id", 0):04x}:{getattr(props, "pci_bus_id", 0):02x}:{getattr(props, "pci_device_id", 0):02x}',
-          'name': props.name, 'host': socket.gethostname()}
-    if world > 1:
-        everyone = [None] * world
-        dist.all_gather_object(everyone, me)
-        dist_info = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks': everyone,
-                     'distinct_devices': len({(e['host'], e['uuid'] or e['pci_bus_id'], e['device_index']) for e in everyone})}
-    else:
-        dist_info = {'backend': None, 'world_size': 1, 'ranks': [me], 'distinct_devices': 1}
+    dist_info = distributed.describe_job(eng.device)
 
     if rank == 0:
         value = S_total * T * args.steps / elapsed

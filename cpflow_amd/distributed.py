@@ -84,3 +84,23 @@ def _all_gather_list(full, pad, size, group):
     chunks = [torch.empty_like(pad) for _ in range(size)]
     dist.all_gather(chunks, pad, group=group)
     full.copy_(torch.cat(chunks, dim=0))
+
+
+def describe_job(device=None):
+    """What torch.distributed sees of this job, gathered from every rank: backend, world size, and per rank the device index,
+    UUID, PCI bus id and host - so that a benchmark line can show N ranks on N distinct GPUs (bench.py `distributed`).
+    Every rank must call it (one object all-gather); without a process group it describes the single process."""
+    import socket
+    me = {'rank': world()[0], 'device_index': None, 'uuid': '', 'pci_bus_id': '', 'name': 'cpu', 'host': socket.gethostname()}
+    if device is not None and torch.cuda.is_available():
+        dev = torch.device(device)
+        props = torch.cuda.get_device_properties(dev)
+        me.update(device_index=dev.index, uuid=str(getattr(props, 'uuid', '')), name=props.name,
+                  pci_bus_id=f'{getattr(props, "pci_domain_id", 0):04x}:{getattr(props, "pci_bus_id", 0):02x}:{getattr(props, "pci_device_id", 0):02x}')
+    rank, size = world()
+    if size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return {'backend': None, 'world_size': 1, 'ranks': [me], 'distinct_devices': 1}
+    everyone = [None] * size
+    dist.all_gather_object(everyone, me)
+    distinct = len({(e['host'], e['uuid'] or e['pci_bus_id'], e['device_index']) for e in everyone})
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks': everyone, 'distinct_devices': distinct}

@@ -34,6 +34,9 @@ def _worker(rank, size, port, S, q):
         local = {k: v[first:first + count] for k, v in full.items()}
         out = distributed.gather_samples(local, S)
         ok = all(out[k].dtype == full[k].dtype and torch.equal(out[k], full[k]) for k in full)
+        # the job description bench.py prints: every rank calls it, every rank gets the same picture
+        info = distributed.describe_job(None)
+        ok = ok and info['backend'] == 'gloo' and info['world_size'] == size and [e['rank'] for e in info['ranks']] == list(range(size))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

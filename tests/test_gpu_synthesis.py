@@ -276,6 +276,9 @@ def test_rccl_collective_path_single_rank():
         got = distributed.gather_samples(fields, 9, force_collective=True)
         for k in fields:
             assert got[k].dtype == fields[k].dtype and torch.equal(got[k], fields[k])
+        info = distributed.describe_job(eng.device)           # the object all-gather of the bench line, over RCCL
+        assert info['backend'] == 'nccl' and info['world_size'] == 1 and info['distinct_devices'] == 1
+        assert info['ranks'][0]['device_index'] == eng.device.index and info['ranks'][0]['uuid']
         dist.barrier()
     finally:
         dist.destroy_process_group()

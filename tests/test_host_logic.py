@@ -242,3 +242,23 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'host_sanitize.sh'), str(tmp_path / 'san')], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert 'host sanitize driver: 0 failure(s)' in r.stdout and 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr
+
+
+def test_generated_dense_asm_header_is_current(tmp_path):
+    """cpflow_amd/csrc/cpf_dense_asm.h is generated (tools/gen_dense_asm.py): the committed file must be what the generator
+    writes, and its two groups must be the 32-instruction lock-step forms the kernel's comments describe."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_dense_asm', os.path.join(ROOT, 'tools', 'gen_dense_asm.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = gen.HEADER % (gen.c_string(gen.group(False)), gen.c_string(gen.group(True)))
+    assert open(os.path.join(ROOT, 'cpflow_amd', 'csrc', 'cpf_dense_asm.h')).read() == want
+    for adj in (False, True):
+        g = gen.group(adj)
+        assert len(g) == 32 and sum(l.startswith('v_pk_mul_f32') for l in g) == 4
+        # every instruction reads the result of the instruction four before it at the earliest (no back-to-back dependence)
+        for k in range(1, 32):
+            assert g[k].split()[1] != g[k - 1].split()[1]
+        # operand 8 + index: forward G[4 i + j], adjoint G[4 j + i]
+        used = sorted({int(l.split('%')[2].split(',')[0]) for l in g})
+        assert used == list(range(8, 24))
