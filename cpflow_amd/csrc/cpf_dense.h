@@ -415,57 +415,7 @@ __device__ __forceinline__ float rot_reg_grad(const f2 (&p)[E], const f2 (&c)[E]
         default: break;                                                                   \
     }
 
-// ---- reduction of the 16 complex environment partials over the wave ------------------------------------------------
-// 32 per-lane values -> value v summed over all 64 lanes, left in LDS dst[v].  Lane bits 5 and 4 by permlane swaps (one
-// swap + one add settle TWO values), then the 8-value DPP reduce-scatter of cpf_blocks.h over bits 2, 3, 0, 1.
-// dst_of_lane: where this lane's final value goes (dense_env_dst).
-__device__ __forceinline__ int dense_env_dst(int lane) {
-    // after the bit-5 stage register r holds value 2 r + (lane bit 5); after the bit-4 stage register r holds value
-    // 4 r + 2 (lane bit 4) + (lane bit 5) of the previous numbering; reduce8 then leaves value index k = reduce8 slot
-    const int k = 4 * (lane & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);     // register index r (0..7) this lane ends with
-    return 4 * k + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
-}
-__device__ __forceinline__ void dense_env_reduce(const f2 (&m)[16], float* dst, int lane, int dst_lane) {
-    float v[32];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { v[2 * i] = m[i].x; v[2 * i + 1] = m[i].y; }
-    float w[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {                       // bit 5: values 2r (kept by the low half), 2r + 1 (high half)
-        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * r]), __float_as_uint(v[2 * r + 1]), false, false);
-        w[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-    }
-    float u[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {                        // bit 4
-        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[2 * r]), __float_as_uint(w[2 * r + 1]), false, false);
-        u[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-    }
-    // bits 2, 3 (reduce-scatter 8 -> 2), bit 0 (2 -> 1), bit 1 (sum): as reduce8_rows, but the 16-lane rows already hold
-    // different values, so every lane's result is final: one store per lane (lanes l and l ^ 2 store the same word)
-    float e0, e1, e2, e3, f0, f1;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %5, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
-        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(f0), "=&v"(f1)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]));
-    const bool b0 = lane & 1;
-    const float keep = b0 ? f1 : f0, give = b0 ? f0 : f1;
-    float r = keep + dppz<0xB1>(give);
-    r += dppz<0x4E>(r);
-    dst[dst_lane] = r;
-}
-
+// ---- reduction of the environment partials over the wave -----------------------------------------------------------
 // 16 values (8 complex accumulators, one half of the environment; value 2 k + c = component c of m[k]): value v summed over
 // the wave, left in dst[v].  Lane bits 5 and 4 by permlane swaps of the SAME component of two neighbouring accumulators, so
 // that one v_pk_add_f32 settles four values (2 swaps + 1 add per 4 values), then the 4-value DPP reduce-scatter over bits 2, 3
@@ -506,6 +456,13 @@ __device__ __forceinline__ void dense_env_reduce16(const f2 (&m)[8], float* dst,
     float r = f0 + dppz<0xB1>(f0);                       // bits 0, 1: plain sums (four lanes end with the same value)
     r += dppz<0x4E>(r);
     dst[dst_lane] = r;
+}
+
+// all 16 accumulators (layouts that accumulate the environment in one pass): the two halves in turn
+__device__ __forceinline__ void dense_env_reduce32(const f2 (&m)[16], float* dst, int dst_lane) {
+    const f2 lo[8] = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]}, hi[8] = {m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]};
+    dense_env_reduce16(lo, dst, dst_lane);
+    dense_env_reduce16(hi, dst + 16, dst_lane);
 }
 
 // ---- LDS map (float offsets) -------------------------------------------------------------------------------------------
@@ -562,7 +519,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     const int col = L::col_index(lane, wave);
-    const int env_dst = HALVES ? dense_env_dst16(lane) : dense_env_dst(lane), surf_dst = reduce8_dst_lane(lane);
+    const int env_dst = dense_env_dst16(lane), surf_dst = reduce8_dst_lane(lane);
     // target element of (lane, e): one 32-bit byte offset per lane + a compile-time offset per e against the scalar base
     // pointer (64-bit per-element addresses would be hoisted out of the step loop: 2 E registers for the whole run)
     const char* tbase = reinterpret_cast<const char*>(a.target);
@@ -814,7 +771,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             } else if constexpr (SG) {
                 f2 m[16];
                 dense_backward_s<E, RA, RB, 0>(psi, cot, g, m);
-                dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+                dense_env_reduce32(m, env_w + 32 * b, env_dst);
             } else if constexpr (HALVES) {
                 f2 m[8];
 #pragma unroll
@@ -832,7 +789,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
                 for (int i = 0; i < 16; i++) m[i] = f2{0.f, 0.f};
                 dense_backward<E, RA, RB, 0>(psi, cot, g, m);
                 prefetch(g);
-                dense_env_reduce(m, env_w + 32 * b, lane, env_dst);
+                dense_env_reduce32(m, env_w + 32 * b, env_dst);
             }
         };
         if constexpr (LL == 0) {

@@ -39,6 +39,8 @@ def configs():
     c['cfg3'] = c['cfg3'][:3] + ([512, 4096],)
     c['n5'] = ([[0, 1], [1, 2], [2, 3], [3, 4]], 36, rand_u(5, 0), [1000])
     c['n4star'] = ([[0, 1], [0, 2], [0, 3]], 23, rand_u(4, 1), [500])
+    c['n5k86'] = ([[0, 1], [1, 2], [2, 3], [3, 4]], 86, rand_u(5, 2), [1000])          # the shape of paper/results/benchmarks/res_4gt13_91
+    c['n5conn'] = ([[i, j] for i in range(5) for j in range(i + 1, 5)], 57, rand_u(5, 3), [2000])   # ... res_4gt10-v1_81 ('xz' there)
     return c
 
 
