@@ -235,12 +235,12 @@ def test_state_preparation_and_relative_phase_front_end():
     ghz[0] = ghz[15] = 1 / np.sqrt(2)
     syn = Synthesize([[0, 1], [1, 2], [2, 3]], target_state=ghz, label='GHZ_4q_linear')
     res = syn.static(StaticOptions(num_cp_gates=4, accepted_num_cz_gates=6, num_samples=64, r=0.002), save_results=False)
-    assert res.decompositions and min(d.cz_count for d in res.decompositions) <= 4
+    assert res.decompositions and min(d.cz_count for d in res.decompositions) == 3          # the tutorial's result (cell 83): 3 CZ
     for d in res.decompositions:
         assert d.loss < 1e-5 and abs(abs(np.vdot(ghz, d.unitary[:, 0])) - 1) < 1e-5
     syn = Synthesize([[0, 1], [1, 2], [0, 2]], unitary_loss_func=RelativePhaseLoss(TOFF3), label='relative_toff3')
     res = syn.static(StaticOptions(num_cp_gates=6, accepted_num_cz_gates=6, num_samples=64, r=0.002), save_results=False)
-    assert res.decompositions and min(d.cz_count for d in res.decompositions) <= 4
+    assert res.decompositions and min(d.cz_count for d in res.decompositions) == 3          # the tutorial's result (cell 91): 3 CZ
     d = min(res.decompositions, key=lambda x: x.cz_count)
     m = TOFF3.conj().T @ d.unitary
     assert np.abs(m - np.diag(np.diag(m))).max() < 1e-2        # V^dagger U is diagonal
