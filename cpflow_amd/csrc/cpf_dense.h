@@ -494,7 +494,9 @@ struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot, surf_mask; f
 
 // UD... = the layer as (up, dn) pairs (block b sits on pair b mod length): the block loops are then straight-line code per
 // layer with compile-time register bits and exchanges.  Empty UD: any circuit, every block dispatched through the table.
-template <int NQ, int LW, int... UD>
+// ROT: the rotation string and entangler as a compile-time code (cpf_blocks.h rot_pack / rot_with_ent) for the per-block
+// 4x4 walks, or 0 = read the kinds from the records (any string up to 8 letters).
+template <int NQ, int LW, int ROT, int... UD>
 __device__ __forceinline__ void dense_body(const DenseArgs& da) {
     using L = DLay<NQ, LW>;
     using PL = PairList<UD...>;
@@ -587,7 +589,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
 #ifdef CPF_EXP_NOBUILD            // timing experiment only (wrong results)
             for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Gb[i][j] = dense::mk(i == j ? 1.f : 0.f, th[b] * 1e-9f);
 #else
-            dense::block_matrix(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
+            dense::block_matrix<ROT>(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
 #endif
             const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
             float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
@@ -897,7 +899,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
 #ifdef CPF_EXP_NOCHAIN            // timing experiment only (wrong results)
             gw[g0] = dense::re(Mb[0][0]) + dense::im(Gb[1][1]);
 #else
-            dense::block_gradient(gw + g0, Gb, Mb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec(qu, qd), gw + 3 * qu, gw + 3 * qd);
+            dense::block_gradient<ROT>(gw + g0, Gb, Mb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec(qu, qd), gw + 3 * qu, gw + 3 * qd);
 #endif
         }
         for (int g = tid; g < NS; g += THREADS) {
@@ -959,9 +961,9 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
     }
 }
 
-template <int NQ, int LW, int... UD>
+template <int NQ, int LW, int ROT, int... UD>
 __global__ __launch_bounds__(64 << LW, ((DLay<NQ, LW>::E >= 32 && sizeof...(UD) == 0) ? 1 : 2)) void k_cp_dense(const DenseArgs da) {
-    dense_body<NQ, LW, UD...>(da);
+    dense_body<NQ, LW, ROT, UD...>(da);
 }
 
 }  // namespace cpf

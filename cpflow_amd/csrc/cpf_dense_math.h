@@ -182,10 +182,18 @@ CPF_HD int surf_kind(int k) { return k == 1 ? K_RX : K_RZ; }
 // rec: the block's gate records in program order, 4 floats each {cos, sin, code, -} with code = kind | q0 << 4 | q1 << 8
 // (the generic kernel's LDS records): rec[0] the entangler, then R_g(up), R_g(dn) per rotation letter.
 // `read(g, &c, &s, &kind)` abstracts the record fetch so that device code reads LDS and the CPU test reads an array.
-template <class Rec, class Surf = NoSurf>
+// ROT != 0: the template's rotation string and entangler are compile-time constants (packed as cpf_blocks.h rot_pack /
+// rot_with_ent: letters | kind_i << (4 + 4 i) | entangler << 16): the walks below unroll completely and every three-way
+// choice folds away.  ROT = 0: kinds come with the records at run time (any rotation string up to 8 letters).
+template <int ROT> CPF_HD constexpr int rotc_n(int n_rot) { return ROT ? (ROT & 15) : n_rot; }
+template <int ROT> CPF_HD constexpr int rotc_kind(int i, int runtime_kind) { return ROT ? ((ROT >> (4 + 4 * i)) & 15) : runtime_kind; }
+template <int ROT> CPF_HD constexpr int rotc_ent(int runtime_kind) { return ROT ? K_CP + ((ROT >> 16) & 3) : runtime_kind; }
+
+template <int ROT = 0, class Rec, class Surf = NoSurf>
 CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot, bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf()) {
     float c, s; int kind;
     rec(0, c, s, kind);
+    kind = rotc_ent<ROT>(kind);
     entangler_matrix(G, kind, c, s);
     if (fold_up || fold_dn) {                    // G = E S: start from the identity, S on the rows, then E
 #pragma unroll
@@ -197,16 +205,17 @@ CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot, bool fold_up 
         if (fold_dn) for (int k = 0; k < 3; k++) { surf(1, k, cs, ss); rot_rows<false>(G, surf_kind(k), cs, ss); }
         entangler_rows<false>(G, kind, c, s);
     }
-    for (int i = 0; i < n_rot; i++) {
+#pragma unroll
+    for (int i = 0; i < rotc_n<ROT>(n_rot); i++) {
         rec(1 + 2 * i, c, s, kind);
-        rot_rows<true>(G, kind, c, s);
+        rot_rows<true>(G, rotc_kind<ROT>(i, kind), c, s);
         rec(2 + 2 * i, c, s, kind);
-        rot_rows<false>(G, kind, c, s);
+        rot_rows<false>(G, rotc_kind<ROT>(i, kind), c, s);
     }
 }
 // grad[0] = entangler angle (CP only, else 0), grad[1 + k] = rotation k in program order.  G = the block matrix.
 // gs_up[k] / gs_dn[k] (k = 0, 1, 2): gradients of the folded surface angles (written only for a folded side).
-template <class Rec, class Surf = NoSurf>
+template <int ROT = 0, class Rec, class Surf = NoSurf>
 CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot,
                            bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf(), float* gs_up = nullptr, float* gs_dn = nullptr) {
     cx X[4][4], Z[4][4];
@@ -215,17 +224,21 @@ CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4]
 #pragma unroll
         for (int j = 0; j < 4; j++) { X[i][j] = G[i][j]; Z[i][j] = M[j][i]; }
     float c, s; int kind;
-    for (int i = n_rot - 1; i >= 0; i--) {
+#pragma unroll
+    for (int i = rotc_n<ROT>(n_rot) - 1; i >= 0; i--) {
         rec(2 + 2 * i, c, s, kind);                       // R_i(dn), the later of the pair
-        grad[2 + 2 * i] = im_trace_sigma<false>(X, Z, kind);
-        rot_rows<false>(X, kind, c, -s);
-        rot_cols<false>(Z, kind, c, s);
+        const int kd = rotc_kind<ROT>(i, kind);
+        grad[2 + 2 * i] = im_trace_sigma<false>(X, Z, kd);
+        rot_rows<false>(X, kd, c, -s);
+        rot_cols<false>(Z, kd, c, s);
         rec(1 + 2 * i, c, s, kind);                       // R_i(up)
-        grad[1 + 2 * i] = im_trace_sigma<true>(X, Z, kind);
-        rot_rows<true>(X, kind, c, -s);
-        rot_cols<true>(Z, kind, c, s);
+        const int ku = rotc_kind<ROT>(i, kind);
+        grad[1 + 2 * i] = im_trace_sigma<true>(X, Z, ku);
+        rot_rows<true>(X, ku, c, -s);
+        rot_cols<true>(Z, ku, c, s);
     }
     rec(0, c, s, kind);
+    kind = rotc_ent<ROT>(kind);
     // here X = E S and Z = M^T A_m .. A_1.  dE/da = i |11><11| E  ->  dL/da = 2 Re(i (X Z)[3][3]) = -2 Im (X Z)[3][3]
     // (S = 1: X[3][j] = e^{ia} delta_j3, i.e. -2 Im(e^{ia} Z[3][3]))
     cx a33 = mk(0.f, 0.f);

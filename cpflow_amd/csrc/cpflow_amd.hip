@@ -351,15 +351,23 @@ int dense_table(cpf_plan* plan, DevBuf& tab) {
     return 0;
 }
 // layers with an ahead-of-time specialised instance (cpf_dense_aot.hip)
-bool dense_has_aot(int nq, int lw, const std::vector<int>& ud) {
+// rotation code of the plan for the dense kernel's compile-time walks (cpf_blocks.h), 0 when it has more than 3 letters
+int dense_rot_code(const cpf_plan* plan) {
+    if (plan->n_rot > 3) return 0;
+    int kinds[3] = {0, 0, 0};
+    for (int i = 0; i < plan->n_rot; i++) kinds[i] = plan->rot[i] == 'x' ? cpf::OP_RX : (plan->rot[i] == 'y' ? cpf::OP_RY : cpf::OP_RZ);
+    return cpf::rot_with_ent(cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]), plan->entangler == CPF_ENTANGLER_CZ ? 1 : (plan->entangler == CPF_ENTANGLER_CX ? 2 : 0));
+}
+bool dense_has_aot(int nq, int lw, int rot, const std::vector<int>& ud) {
+    if (rot != CPF_DENSE_AOT_ROT) return false;
     static const std::vector<std::pair<int, std::vector<int>>> aot = {
         {6 * 8 + 1, {0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}}, {6 * 8 + 2, {0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}},
         {5 * 8 + 0, {0, 1, 1, 2, 2, 3, 3, 4}}, {4 * 8 + 0, {0, 1, 1, 2, 2, 3}}};
     for (const auto& kv : aot) if (kv.first == nq * 8 + lw && kv.second == ud) return true;
     return false;
 }
-cpf_jit::Spec dense_jit_spec(int nq, int lw, const std::vector<int>& ud) {
-    cpf_jit::Spec spec{"cpf_dense.h", cpf_jit::body_expr("dense_body", {nq, lw}, ud), 64 << lw};
+cpf_jit::Spec dense_jit_spec(int nq, int lw, int rot, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_dense.h", cpf_jit::body_expr("dense_body", {nq, lw, rot}, ud), 64 << lw};
     spec.arg = "cpf::DenseArgs";
     spec.min_waves = 2;                       // layer-specialised sweeps fit 256 registers (two waves per SIMD)
     spec.flags = {CPF_DENSE_MLLVM_FLAGS};
@@ -413,12 +421,13 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     hipError_t e = hipSuccess;
     const std::string waves = " waves=" + std::to_string(wps);
     if (specialised) {
-        const bool have_aot = dense_has_aot(nq, lw, plan->layer_ud);
+        const int rot = dense_rot_code(plan);
+        const bool have_aot = dense_has_aot(nq, lw, rot, plan->layer_ud);
         // a module kernel cannot opt in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute takes a registered host
         // symbol): such shapes (K >~ 100 at 6 qubits) take the ahead-of-time table kernel below
         if (!have_aot && plan->use_jit && lds > 64 * 1024) plan->jit_note = "LDS footprint above 64 KiB";
         if (!have_aot && plan->use_jit && lds <= 64 * 1024) {
-            const cpf_jit::Spec spec = dense_jit_spec(nq, lw, plan->layer_ud);
+            const cpf_jit::Spec spec = dense_jit_spec(nq, lw, rot, plan->layer_ud);
             const cpf_jit::Kernel& k = cpf_jit::get(plan->device, spec);
             if (k.fn) {
                 cpf::DenseArgs args = da;
@@ -431,7 +440,7 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
             if (k.error.find("forbidden") != std::string::npos) return fail(-30, "%s", k.error.c_str());
         }
     }
-    const int kind = cpf_dense_launch_aot(nq, lw, plan->layer_ud, specialised, da, S, lds, stream, &e);
+    const int kind = cpf_dense_launch_aot(nq, lw, dense_rot_code(plan), plan->layer_ud, specialised, da, S, lds, stream, &e);
     if (kind == 0) return fail(-2, "no dense kernel for %d qubits, %d waves", nq, wps);
     if (e != hipSuccess) return fail((int)e, "dense kernel launch failed: %s", hipGetErrorString(e));
     plan->variant = std::string(kind == 1 ? "dense/aot" : "dense/table") + waves + (kind == 2 && !plan->jit_note.empty() ? " (" + plan->jit_note + ")" : "");
@@ -913,8 +922,8 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     const int loss_kind = pb->loss_kind == CPF_LOSS_RELATIVE_PHASE ? 2 : 0;
     if (dense_wanted(&pl, cpf::MODE_OPTIMIZE)) {          // the dense-block kernel serves this shape: its layer-specialised instance
         const int lw = dense_lw(&pl, num_samples);
-        if (dense_specialised(&pl) && !dense_has_aot(pl.NQ, lw, pl.layer_ud)) {
-            const cpf_jit::Spec spec = dense_jit_spec(pl.NQ, lw, pl.layer_ud);
+        if (dense_specialised(&pl) && !dense_has_aot(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud)) {
+            const cpf_jit::Spec spec = dense_jit_spec(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud);
             const cpf_jit::Code code = cpf_jit::build(spec);
             if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
             if (int rc = precompile_landed(code, spec.body)) return rc;

@@ -38,3 +38,19 @@ extern "C" void dm_block_gradient_folded(const float* rec, int n_rot, int fold_u
     }
     block_gradient(grad, g, m, ArrRec{rec}, n_rot, fold_up != 0, fold_dn != 0, ArrSurf{surf}, gs_up, gs_dn);
 }
+
+// compile-time rotation string 'xyz' with CP blocks (ROT = 8451 = rot_pack(3, RX, RY, RZ)): must equal the run-time path
+extern "C" void dm_block_matrix_xyz(const float* rec, int fold_up, int fold_dn, const float* surf, float* G) {
+    cx g[4][4];
+    block_matrix<8451>(g, ArrRec{rec}, 3, fold_up != 0, fold_dn != 0, ArrSurf{surf});
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { G[2 * (4 * i + j)] = re(g[i][j]); G[2 * (4 * i + j) + 1] = im(g[i][j]); }
+}
+extern "C" void dm_block_gradient_xyz(const float* rec, int fold_up, int fold_dn, const float* surf, const float* G, const float* M,
+                                      float* grad, float* gs_up, float* gs_dn) {
+    cx g[4][4], m[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        g[i][j] = mk(G[2 * (4 * i + j)], G[2 * (4 * i + j) + 1]);
+        m[i][j] = mk(M[2 * (4 * i + j)], M[2 * (4 * i + j) + 1]);
+    }
+    block_gradient<8451>(grad, g, m, ArrRec{rec}, 3, fold_up != 0, fold_dn != 0, ArrSurf{surf}, gs_up, gs_dn);
+}

@@ -130,3 +130,28 @@ def test_block_with_folded_surface_gates(shim, ent, fold, kinds):
                 qm[side, k] -= h
                 want = (L(angles, qp) - L(angles, qm)) / (2 * h)
                 assert abs(got[k] - want) < 3e-4 * scale, (side, k, got, want)
+
+
+@pytest.mark.parametrize('fold', [(0, 0), (1, 1), (0, 1)])
+def test_compile_time_rotation_string_equals_run_time_path(shim, fold):
+    """The walks specialised on 'xyz' + CP (template argument ROT = 8451, what the ahead-of-time dense kernels use) give
+    bit for bit what the run-time-kind path gives on the same records."""
+    rng = np.random.default_rng(3 + fold[0] + 2 * fold[1])
+    kinds = (K_RX, K_RY, K_RZ)
+    for _ in range(4):
+        angles = rng.uniform(-4, 7, 7)
+        sa = rng.uniform(-4, 7, (2, 3))
+        rec = records(K_CP, kinds, angles)
+        surf = np.stack([np.cos(sa / 2), np.sin(sa / 2)], -1).astype(np.float32).reshape(-1)
+        G0, G1 = np.zeros(32, np.float32), np.zeros(32, np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        shim.dm_block_matrix_folded(p(rec), 3, fold[0], fold[1], p(surf), p(G0))
+        shim.dm_block_matrix_xyz(p(rec), fold[0], fold[1], p(surf), p(G1))
+        assert (G0 == G1).all()
+        M = (rng.normal(size=(4, 4, 2))).astype(np.float32).reshape(-1)
+        out = []
+        for fn, extra in ((shim.dm_block_gradient_folded, (3,)), (shim.dm_block_gradient_xyz, ())):
+            grad, gu, gd = np.zeros(7, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+            fn(p(rec), *extra, fold[0], fold[1], p(surf), p(G0), p(M), p(grad), p(gu), p(gd))
+            out.append(np.concatenate([grad, gu, gd]))
+        assert (out[0] == out[1]).all()
