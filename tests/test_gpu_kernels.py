@@ -612,3 +612,32 @@ def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypa
     out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
     assert not eng0.last_variant().startswith('dense')
     assert np.abs(outf['regloss'] - out0['regloss']).max() < 2e-5
+
+
+@pytest.mark.parametrize('layer,K,how', [([[0, 1], [4, 2]], 3, 'table'), ([[0, 1], [4, 2]], 5, 'jit'), ([[2, 5], [5, 3]], 1, 'table'),
+                                         ([[i, (i + 1) % 6] for i in range(6)], 4, 'jit'), ([[i, (i + 1) % 6] for i in range(6)], 7, 'aot')])
+def test_dense_surface_folding_edge_cases(layer, K, how, tune):
+    """Surface gates are folded into the first block that touches their qubit (cpf_dense_math.h).  Edge cases: qubits no
+    block touches (their gates stay in the sweeps: DenseArgs::surf_mask), a single block, fewer blocks than one layer (only
+    some qubits folded), first touch through the block's second qubit.  Against the float64 oracle, and folding switched off
+    (cpf_set_tuning CPF_DENSE_FOLD = 0) must give the same run up to rounding."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 11)
+    T, S = 8, 4
+    tune.set('CPF_DENSE', '1')
+    tune.set('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
+    kw = dict(num_gd_iterations=T, r=0.004)
+    orc = Oracle(layer, K, target, 'xyz', **kw)
+    init = orc.initial_angles(5, S)
+    ref = orc.run(init, np.float64, keep_history=True)
+    runs = {}
+    for fold in ('1', '0'):
+        tune.set('CPF_DENSE_FOLD', fold)
+        eng = _engine(layer, K, target, 'xyz', **kw)
+        out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+        assert eng.last_variant().startswith({'aot': 'dense/aot', 'table': 'dense/table', 'jit': 'dense/jit(hipcc)'}[how]), eng.last_variant()
+        assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 2e-5
+        assert np.abs(out['history_params'] - ref['history_params']).max() < 2e-4
+        assert np.abs(out['history_params'] - ref['history_params'])[:, :2].max() < 3e-5      # the first gradient, surface angles included
+        runs[fold] = out
+    assert np.abs(runs['1']['history_regloss'] - runs['0']['history_regloss']).max() < 1e-5
