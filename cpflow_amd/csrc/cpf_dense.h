@@ -16,20 +16,28 @@
 // position q: positions 0 .. NRR-1 are register bits, the last NLR qubits sit on the lanes.  A block whose pair
 // involves a lane qubit first exchanges that qubit with a register qubit outside the pair - v_permlane32_swap /
 // v_permlane16_swap move lane bit 5 / 4 against a register bit in ONE instruction per register pair, E per matrix -
-// and exchanges it back afterwards, so that between blocks the layout is always the canonical one.  No DPP, no LDS
-// traffic inside a sweep except the 128-byte G of each block (uniform address, broadcast reads).
+// and exchanges it back afterwards, so that between blocks the layout is always the canonical one.  No DPP and no LDS
+// traffic inside a sweep.
 //
-// One kernel per (qubits, waves per sample) serves every layer, rotation string and entangler: which register bits a
-// block acts on and which exchanges it needs come from a per-block table the host builds (cpf_dense_block), dispatched
-// with scalar branches (one per ~10^3 vector instructions).
+// Instances.  Table-dispatched (<NQ, LW, 0>): one kernel per (qubits, waves per sample) serves every layer, rotation
+// string and entangler without a compiler - which register bits a block acts on and which exchanges it needs come from a
+// per-block table the host builds, dispatched with scalar branches; G is read from LDS into vector registers.
+// Layer-specialised (<NQ, LW, ROT, UD...>, ahead of time for the BASELINE shapes, at run time otherwise): straight-line
+// sweeps per layer, the per-block 4x4 walks unrolled on the rotation string, and (round 3) G in SCALAR registers: the build
+// phase also writes every G to a global scratch, the sweeps read it back with s_load_dwordx16 and every group of four
+// amplitudes is one asm statement of 32 packed instructions whose factors are scalar register pairs (cpf_dense_asm.h).
+//
+// Surface gates (round 3): the first block that touches a qubit carries that qubit's Rz Rx Rz on its input side
+// (cpf_dense_math.h), so the sweeps start from the identity and apply no rotation; qubits no block touches keep the
+// gate-by-gate path (DenseArgs::surf_mask).
 //
 // Phases of one optimiser step (T of them in one launch, one workgroup per sample):
 //   owner    Adam on the angles this thread owns, their (cos, sin) to the gate records        [LDS: th, m, v, rec]
-//   build    thread b builds G_b from the records of block b                                   [LDS: Gm]
-//   forward  psi = I; surface gates (gate by gate, on register bits); blocks b = 0 .. K-1
+//   build    thread b builds G_b from the records of block b (and of the surface gates folded into it)  [LDS: Gm; global: gmat]
+//   forward  psi = I; surface gates of untouched qubits; blocks b = 0 .. K-1
 //   loss     T = sum conj(V) psi over the workgroup; best-iterate tracking
-//   backward C = f V; blocks K-1 .. 0 (fused pass above, M reduced over the wave -> LDS env); surface gates
-//   chain    thread b: angle gradients of block b from M_b (summed over waves) and G_b          [LDS: gw]
+//   backward C = f V; blocks K-1 .. 0 (fused pass above, M reduced over the wave -> LDS env); surface gates of untouched qubits
+//   chain    thread b: angle gradients of block b (and of its folded surface gates) from M_b and G_b   [LDS: gw]
 #pragma once
 #include "cpf_layered.h"
 #include "cpf_dense_math.h"
