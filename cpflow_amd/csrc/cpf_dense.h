@@ -590,27 +590,27 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         // per-lane constants pass through an opaque copy once per step: otherwise everything derived from them (the E
         // identity amplitudes, the E target offsets) is hoisted out of the step loop and occupies registers for the whole run
         asm volatile("" : "+v"(toff_i), "+v"(lane_i), "+v"(col_i));
-        // ================= build: G_b from the gate records, one thread per block
-        for (int b = tid; b < K; b += THREADS) {
+        // ================= build: column j of G_b from the gate records, four neighbouring threads per block (the walk of a
+        // column is a quarter of the matrix's: cpf_dense_math.h "slices")
+        for (int w = tid; w < 4 * K; w += THREADS) {
+            const int b = w >> 2, j = w & 3;
             const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
-            dense::cx Gb[4][4];
+            dense::cx x[4];
 #ifdef CPF_EXP_NOBUILD            // timing experiment only (wrong results)
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Gb[i][j] = dense::mk(i == j ? 1.f : 0.f, th[b] * 1e-9f);
+            for (int i = 0; i < 4; i++) x[i] = dense::mk(i == j ? 1.f : 0.f, th[b] * 1e-9f);
 #else
-            dense::block_matrix<ROT>(Gb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
+            dense::block_matrix_column<ROT>(x, j, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec((z >> 12) & 15, (z >> 16) & 15));
 #endif
             const bool up_low = (z & 256) != 0;            // first qubit on the lower register bit: exchange the index bits
             float2* out = reinterpret_cast<float2*>(smem + lds.gm + 32 * b);
             float2* gout = SG ? reinterpret_cast<float2*>(da.gmat + ((size_t)s_idx * K + b) * 32) : nullptr;
+            const int jj = up_low ? dense::swap_bits2(j) : j;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const dense::cx v = Gb[i][j];
-                    const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
-                    out[4 * ii + jj] = make_float2(dense::re(v), dense::im(v));
-                    if constexpr (SG) gout[4 * ii + jj] = make_float2(dense::re(v), dense::im(v));
-                }
+            for (int i = 0; i < 4; i++) {
+                const int ii = up_low ? dense::swap_bits2(i) : i;
+                out[4 * ii + jj] = make_float2(dense::re(x[i]), dense::im(x[i]));
+                if constexpr (SG) gout[4 * ii + jj] = make_float2(dense::re(x[i]), dense::im(x[i]));
+            }
         }
         if constexpr (SG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the matrices have reached L2 ...
         lds_sync<WPS>();
@@ -883,32 +883,48 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
         }
         lds_sync<WPS>();
 
-        // ================= chain: the angle gradients of block b from its environment; surface gradients
-        for (int b = tid; b < K; b += THREADS) {
+        // ================= chain: the angle gradients of block b from its environment, four neighbouring threads per block:
+        // thread j walks column j of G_b and row j of M_b^T and contributes one term to every trace (two-step quad sum)
+        for (int w = tid; w < 4 * K; w += THREADS) {
+            const int b = w >> 2, j = w & 3;
             const int z = blk[4 * b + 2], g0 = blk[4 * b + 3];
-            const bool up_low = (z & 256) != 0;
-            dense::cx Gb[4][4], Mb[4][4];
+            const bool up_low = (z & 256) != 0, fu = (z & 512) != 0, fd = (z & 1024) != 0;
+            const int jj = up_low ? dense::swap_bits2(j) : j;
+            dense::cx x[4], zr[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int ii = up_low ? dense::swap_bits2(i) : i, jj = up_low ? dense::swap_bits2(j) : j;
-                    float2 mv = make_float2(0.f, 0.f);
-                    for (int w = 0; w < WPS; w++) {
-                        const float2 t = *reinterpret_cast<const float2*>(smem + lds.env + (w * K + b) * 32 + 2 * (4 * ii + jj));
-                        mv.x += t.x; mv.y += t.y;
-                    }
-                    Mb[i][j] = dense::mk(mv.x, mv.y);
-                    const float2 gv = *reinterpret_cast<const float2*>(smem + lds.gm + 32 * b + 2 * (4 * ii + jj));
-                    Gb[i][j] = dense::mk(gv.x, gv.y);
+            for (int i = 0; i < 4; i++) {
+                const int ii = up_low ? dense::swap_bits2(i) : i;
+                float2 mv = make_float2(0.f, 0.f);
+                for (int wv = 0; wv < WPS; wv++) {
+                    const float2 t = *reinterpret_cast<const float2*>(smem + lds.env + (wv * K + b) * 32 + 2 * (4 * ii + jj));
+                    mv.x += t.x; mv.y += t.y;
                 }
+                zr[i] = dense::mk(mv.x, mv.y);                                   // Z[j][i] = M[i][j]
+                const float2 gv = *reinterpret_cast<const float2*>(smem + lds.gm + 32 * b + 2 * (4 * ii + jj));
+                x[i] = dense::mk(gv.x, gv.y);
+            }
             const int qu = (z >> 12) & 15, qd = (z >> 16) & 15;
-            // gate g0 + i carries angle i of the block; a folded surface gate's angles are gates 3 q .. 3 q + 2
+            float gpart[dense::MAX_BLOCK_ANGLES], pu[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
 #ifdef CPF_EXP_NOCHAIN            // timing experiment only (wrong results)
-            gw[g0] = dense::re(Mb[0][0]) + dense::im(Gb[1][1]);
+            gpart[0] = dense::re(zr[0]) + dense::im(x[1]);
 #else
-            dense::block_gradient<ROT>(gw + g0, Gb, Mb, block_rec(g0), NR, (z & 512) != 0, (z & 1024) != 0, surf_rec(qu, qd), gw + 3 * qu, gw + 3 * qd);
+            dense::block_gradient_slice<ROT>(gpart, x, zr, block_rec(g0), NR, fu, fd, surf_rec(qu, qd), pu, pd);
 #endif
+            auto quad_sum = [](float v) __attribute__((always_inline)) { v += xor_lane<0>(v); return v + xor_lane<1>(v); };
+            // gate g0 + i carries angle i of the block; a folded surface gate's angles are gates 3 q .. 3 q + 2
+            const int na = 1 + 2 * dense::rotc_n<ROT>(NR);
+#pragma unroll
+            for (int k = 0; k < (ROT ? 1 + 2 * (ROT & 15) : dense::MAX_BLOCK_ANGLES); k++) {
+                if (k < na) { const float v = quad_sum(gpart[k]); if (j == 0) gw[g0 + k] = v; }
+            }
+            if (fu) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float v = quad_sum(pu[k]); if (j == 0) gw[3 * qu + k] = v; }
+            }
+            if (fd) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float v = quad_sum(pd[k]); if (j == 0) gw[3 * qd + k] = v; }
+            }
         }
         for (int g = tid; g < NS; g += THREADS) {
             if (!((da.surf_mask >> (g / 3)) & 1)) continue;              // written by the block the gate is folded into

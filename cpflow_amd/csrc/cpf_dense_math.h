@@ -4,7 +4,7 @@
 // One entangling block of the template (cpflow/main.py:69-82) acts on its qubit pair as the 4x4 matrix
 //     G = A_m ... A_2 A_1 E,     E = CP(a) | CZ | CX,   A_1 = R_g0(up), A_2 = R_g0(dn), A_3 = R_g1(up), ...
 // in the basis index 2 * up + dn (up = first qubit of the placement, gates.py / circuit_assembly.py:16-28).
-//   block_matrix      G from the block's (cos, sin) records (optionally with the surface gates of its qubits folded in:
+//   block_matrix      G from the block's (cos, sin) records (column by column: block_matrix_column; optionally with the surface gates of its qubits folded in:
 //                     G' = G (S_up (x) S_dn), see "Surface gates folded into a block")         [before the forward sweep]
 //   block_gradient    the block's angle gradients from the 4x4 environment
 //                         M_ij = sum_{other qubits, columns} conj(C_i) psi_j        [after the backward sweep]
@@ -57,117 +57,65 @@ template <bool NEG> CPF_HD cx acc_same(cx acc, cx x, cx z) { return NEG ? mk(acc
 CPF_HD cx sel(bool t, cx a, cx b) { return t ? a : b; }
 #endif
 
-// X <- R X (rows) for R = exp(-i a sigma / 2) on the up (bit 1) or dn (bit 0) index; (c, s) = (cos a/2, sin a/2);
-// s -> -s gives the inverse.  X[r][j], r = 2 up + dn.
-template <bool ON_UP>
-CPF_HD void rot_rows(cx (&X)[4][4], int kind, float c, float s) {
-    constexpr int b = ON_UP ? 2 : 1;
-#pragma unroll
-    for (int r0 = 0; r0 < 4; r0++) {
-        if (r0 & b) continue;
-        const int r1 = r0 | b;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const cx x0 = X[r0][j], x1 = X[r1][j];
-            if (kind == K_RX) {            // [[c, -is], [-is, c]]
-                X[r0][j] = lin_swap(c, x0, s, -s, x1);
-                X[r1][j] = lin_swap(c, x1, s, -s, x0);
-            } else if (kind == K_RY) {     // [[c, -s], [s, c]]
-                X[r0][j] = lin(c, x0, -s, x1);
-                X[r1][j] = lin(c, x1, s, x0);
-            } else {                       // diag(c - is, c + is)
-                X[r0][j] = lin_swap(c, x0, s, -s, x0);
-                X[r1][j] = lin_swap(c, x1, -s, s, x1);
-            }
-        }
-    }
-}
-// Z <- Z R (columns)
-template <bool ON_UP>
-CPF_HD void rot_cols(cx (&Z)[4][4], int kind, float c, float s) {
-    constexpr int b = ON_UP ? 2 : 1;
-#pragma unroll
-    for (int c0 = 0; c0 < 4; c0++) {
-        if (c0 & b) continue;
-        const int c1 = c0 | b;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const cx z0 = Z[i][c0], z1 = Z[i][c1];
-            if (kind == K_RX) {            // (Z R)[i][c0] = c z0 - i s z1, [i][c1] = -i s z0 + c z1
-                Z[i][c0] = lin_swap(c, z0, s, -s, z1);
-                Z[i][c1] = lin_swap(c, z1, s, -s, z0);
-            } else if (kind == K_RY) {     // [i][c0] = c z0 + s z1, [i][c1] = -s z0 + c z1
-                Z[i][c0] = lin(c, z0, s, z1);
-                Z[i][c1] = lin(c, z1, -s, z0);
-            } else {
-                Z[i][c0] = lin_swap(c, z0, s, -s, z0);
-                Z[i][c1] = lin_swap(c, z1, -s, s, z1);
-            }
-        }
-    }
-}
-// Im tr(sigma X Z), sigma the Pauli matrix of `kind` on the up / dn index
-template <bool ON_UP>
-CPF_HD float im_trace_sigma(const cx (&X)[4][4], const cx (&Z)[4][4], int kind) {
-    constexpr int b = ON_UP ? 2 : 1;
-    // four accumulators (one per row r) advance in turn: a packed multiply-add that reads the result of the instruction
-    // right before it is padded with an s_nop on this chip
-    cx a4[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const bool hi = (r & b) != 0;
-            const cx z = Z[j][r];
-            if (kind == K_RX) {            // (sigma X)[r] = X[r ^ b]:  Im(x z) = x.re z.im + x.im z.re
-                a4[r] = acc_swap<false>(a4[r], X[r ^ b][j], z);
-            } else if (kind == K_RY) {     // (sigma X)[r] = -i X[r ^ b] (bit clear), +i X[r ^ b] (bit set):  Im(+-i x z) = +-Re(x z)
-                a4[r] = hi ? acc_same<false>(a4[r], X[r ^ b][j], z) : acc_same<true>(a4[r], X[r ^ b][j], z);
-            } else {                       // (sigma X)[r] = +X[r] (bit clear), -X[r] (bit set)
-                a4[r] = hi ? acc_swap<true>(a4[r], X[r][j], z) : acc_swap<false>(a4[r], X[r][j], z);
-            }
-        }
-    }
-    const cx acc = mk((re(a4[0]) + re(a4[1])) + (re(a4[2]) + re(a4[3])), (im(a4[0]) + im(a4[1])) + (im(a4[2]) + im(a4[3])));
-    return kind == K_RY ? re(acc) - im(acc) : re(acc) + im(acc);      // Re(x z) = x.re z.re - x.im z.im
-}
+// ---- slices -------------------------------------------------------------------------------------------------------
+// Row operations X <- R X act on every COLUMN of X separately, column operations Z <- Z R on every ROW of Z separately, and
+// Im tr(sigma X Z) = sum_j [a term of column j of X and row j of Z].  So a block's walks split four ways: slice j holds
+// x[r] = X[r][j] and z[c] = Z[j][c], applies every operation to its two 4-vectors and contributes one term per trace.
+// On the device four neighbouring lanes take the four slices of a block (the traces meet in a two-step quad sum): the walks
+// run on one wave while the sample's other lanes wait, so their length is serial time, and a slice is a quarter of it.
+// On the CPU the whole-matrix functions below loop over the slices.
 
-// Entangler as the starting matrix.  (cc, sc) = (cos a, sin a) of the CP angle (unused for CZ / CX).
-CPF_HD void entangler_matrix(cx (&X)[4][4], int ent, float cc, float sc) {
+// v <- R v for a column of X (COLS = false) or v <- v R for a row of Z (COLS = true); R = exp(-i a sigma / 2) on the up
+// (index bit 1) or dn (bit 0) qubit, (c, s) = (cos a/2, sin a/2); s -> -s gives the inverse.
+template <bool ON_UP, bool COLS>
+CPF_HD void rot_slice(cx (&v)[4], int kind, float c, float s) {
+    constexpr int b = ON_UP ? 2 : 1;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) X[i][j] = mk(0.f, 0.f);
-    X[0][0] = mk(1.f, 0.f); X[1][1] = mk(1.f, 0.f);
-    // selects, not conditional stores (a store under a branch makes the compiler index the array dynamically -> scratch)
-    const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;       // CX: control = up, target = dn (gates.py:40-43)
-    X[2][2] = mk(is_cx ? 0.f : 1.f, 0.f); X[2][3] = mk(is_cx ? 1.f : 0.f, 0.f);
-    X[3][2] = mk(is_cx ? 1.f : 0.f, 0.f);
-    X[3][3] = mk(is_cx ? 0.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : sc);
+    for (int i0 = 0; i0 < 4; i0++) {
+        if (i0 & b) continue;
+        const int i1 = i0 | b;
+        const cx v0 = v[i0], v1 = v[i1];
+        if (kind == K_RX) {                // rows: [[c, -is], [-is, c]] v;  columns: the same (R is symmetric)
+            v[i0] = lin_swap(c, v0, s, -s, v1);
+            v[i1] = lin_swap(c, v1, s, -s, v0);
+        } else if (kind == K_RY) {         // rows: [[c, -s], [s, c]] v;  columns: v [[c, -s], [s, c]] = (c v0 + s v1, -s v0 + c v1)
+            v[i0] = lin(c, v0, COLS ? s : -s, v1);
+            v[i1] = lin(c, v1, COLS ? -s : s, v0);
+        } else {                           // diag(c - is, c + is)
+            v[i0] = lin_swap(c, v0, s, -s, v0);
+            v[i1] = lin_swap(c, v1, -s, s, v1);
+        }
+    }
 }
-
-// X <- E X (ADJ: E^+ X) on the rows, for the entangler `ent` with (cc, sc) = (cos a, sin a) of the CP angle
+// slice j's term of Im tr(sigma X Z): sum_r (sigma X)[r][j] Z[j][r], sigma the Pauli matrix of `kind` on the up / dn index
+template <bool ON_UP>
+CPF_HD float im_trace_slice(const cx (&x)[4], const cx (&z)[4], int kind) {
+    constexpr int b = ON_UP ? 2 : 1;
+    // two accumulators advance in turn: a packed multiply-add that reads the result of the instruction right before it is
+    // padded with an s_nop on this chip
+    cx a2[2] = {mk(0.f, 0.f), mk(0.f, 0.f)};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool hi = (r & b) != 0;
+        if (kind == K_RX) {                // (sigma X)[r] = X[r ^ b]:  Im(x z) = x.re z.im + x.im z.re
+            a2[r & 1] = acc_swap<false>(a2[r & 1], x[r ^ b], z[r]);
+        } else if (kind == K_RY) {         // (sigma X)[r] = -i X[r ^ b] (bit clear), +i X[r ^ b] (bit set):  Im(+-i x z) = +-Re(x z)
+            a2[r & 1] = hi ? acc_same<false>(a2[r & 1], x[r ^ b], z[r]) : acc_same<true>(a2[r & 1], x[r ^ b], z[r]);
+        } else {                           // (sigma X)[r] = +X[r] (bit clear), -X[r] (bit set)
+            a2[r & 1] = hi ? acc_swap<true>(a2[r & 1], x[r], z[r]) : acc_swap<false>(a2[r & 1], x[r], z[r]);
+        }
+    }
+    const float pr = re(a2[0]) + re(a2[1]), pi = im(a2[0]) + im(a2[1]);
+    return kind == K_RY ? pr - pi : pr + pi;                   // Re(x z) = x.re z.re - x.im z.im
+}
+// v <- E v (column of X; ADJ: E^+ v) or v <- v E (row of Z, ADJ = false): both touch entries 2 and 3 only
 template <bool ADJ>
-CPF_HD void entangler_rows(cx (&X)[4][4], int ent, float cc, float sc) {
+CPF_HD void entangler_slice(cx (&v)[4], int ent, float cc, float sc) {
     const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;
     const cx ph = mk(is_cx ? 1.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : (ADJ ? -sc : sc));
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const cx r2 = X[2][j], r3 = X[3][j];
-        X[2][j] = sel(is_cx, r3, r2);
-        X[3][j] = cmulc(ph, sel(is_cx, r2, r3));
-    }
-}
-// Z <- Z E on the columns
-CPF_HD void entangler_cols(cx (&Z)[4][4], int ent, float cc, float sc) {
-    const bool is_cx = ent == K_CX, is_cz = ent == K_CZ;
-    const cx ph = mk(is_cx ? 1.f : (is_cz ? -1.f : cc), (is_cx || is_cz) ? 0.f : sc);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const cx c2 = Z[i][2], c3 = Z[i][3];
-        Z[i][2] = sel(is_cx, c3, c2);
-        Z[i][3] = cmulc(ph, sel(is_cx, c2, c3));
-    }
+    const cx v2 = v[2], v3 = v[3];
+    v[2] = sel(is_cx, v3, v2);
+    v[3] = cmulc(ph, sel(is_cx, v2, v3));
 }
 
 // Surface gates folded into a block.  The template starts with Rz(t2) Rx(t1) Rz(t0) on every qubit (main.py:122-124);
@@ -189,79 +137,95 @@ template <int ROT> CPF_HD constexpr int rotc_n(int n_rot) { return ROT ? (ROT & 
 template <int ROT> CPF_HD constexpr int rotc_kind(int i, int runtime_kind) { return ROT ? ((ROT >> (4 + 4 * i)) & 15) : runtime_kind; }
 template <int ROT> CPF_HD constexpr int rotc_ent(int runtime_kind) { return ROT ? K_CP + ((ROT >> 16) & 3) : runtime_kind; }
 
+// column j of the block matrix G' = A_m .. A_1 E (S_up (x) S_dn): the unit vector e_j through every row operation
 template <int ROT = 0, class Rec, class Surf = NoSurf>
-CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot, bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf()) {
-    float c, s; int kind;
+CPF_HD void block_matrix_column(cx (&x)[4], int j, const Rec& rec, int n_rot, bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf()) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = mk(i == j ? 1.f : 0.f, 0.f);
+    float c, s, cs, ss; int kind;
+    if (fold_up) for (int k = 0; k < 3; k++) { surf(0, k, cs, ss); rot_slice<true, false>(x, surf_kind(k), cs, ss); }
+    if (fold_dn) for (int k = 0; k < 3; k++) { surf(1, k, cs, ss); rot_slice<false, false>(x, surf_kind(k), cs, ss); }
     rec(0, c, s, kind);
-    kind = rotc_ent<ROT>(kind);
-    entangler_matrix(G, kind, c, s);
-    if (fold_up || fold_dn) {                    // G = E S: start from the identity, S on the rows, then E
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) G[i][j] = mk(i == j ? 1.f : 0.f, 0.f);
-        float cs, ss;
-        if (fold_up) for (int k = 0; k < 3; k++) { surf(0, k, cs, ss); rot_rows<true>(G, surf_kind(k), cs, ss); }
-        if (fold_dn) for (int k = 0; k < 3; k++) { surf(1, k, cs, ss); rot_rows<false>(G, surf_kind(k), cs, ss); }
-        entangler_rows<false>(G, kind, c, s);
-    }
+    entangler_slice<false>(x, rotc_ent<ROT>(kind), c, s);
 #pragma unroll
     for (int i = 0; i < rotc_n<ROT>(n_rot); i++) {
         rec(1 + 2 * i, c, s, kind);
-        rot_rows<true>(G, rotc_kind<ROT>(i, kind), c, s);
+        rot_slice<true, false>(x, rotc_kind<ROT>(i, kind), c, s);
         rec(2 + 2 * i, c, s, kind);
-        rot_rows<false>(G, rotc_kind<ROT>(i, kind), c, s);
+        rot_slice<false, false>(x, rotc_kind<ROT>(i, kind), c, s);
     }
 }
-// grad[0] = entangler angle (CP only, else 0), grad[1 + k] = rotation k in program order.  G = the block matrix.
-// gs_up[k] / gs_dn[k] (k = 0, 1, 2): gradients of the folded surface angles (written only for a folded side).
+// Slice j's share of the block's gradients: x = column j of G', z = row j of M^T (= column j of the environment M).
+// grad[0] = entangler angle (CP only, else 0), grad[1 + k] = rotation k in program order; gs_up[k] / gs_dn[k] (k = 0, 1, 2):
+// the folded surface angles (written only for a folded side).  The four slices' shares add up to the gradients.
 template <int ROT = 0, class Rec, class Surf = NoSurf>
-CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot,
-                           bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf(), float* gs_up = nullptr, float* gs_dn = nullptr) {
-    cx X[4][4], Z[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) { X[i][j] = G[i][j]; Z[i][j] = M[j][i]; }
+CPF_HD void block_gradient_slice(float* grad, cx (&x)[4], cx (&z)[4], const Rec& rec, int n_rot,
+                                 bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf(), float* gs_up = nullptr, float* gs_dn = nullptr) {
     float c, s; int kind;
 #pragma unroll
     for (int i = rotc_n<ROT>(n_rot) - 1; i >= 0; i--) {
         rec(2 + 2 * i, c, s, kind);                       // R_i(dn), the later of the pair
         const int kd = rotc_kind<ROT>(i, kind);
-        grad[2 + 2 * i] = im_trace_sigma<false>(X, Z, kd);
-        rot_rows<false>(X, kd, c, -s);
-        rot_cols<false>(Z, kd, c, s);
+        grad[2 + 2 * i] = im_trace_slice<false>(x, z, kd);
+        rot_slice<false, false>(x, kd, c, -s);
+        rot_slice<false, true>(z, kd, c, s);
         rec(1 + 2 * i, c, s, kind);                       // R_i(up)
         const int ku = rotc_kind<ROT>(i, kind);
-        grad[1 + 2 * i] = im_trace_sigma<true>(X, Z, ku);
-        rot_rows<true>(X, ku, c, -s);
-        rot_cols<true>(Z, ku, c, s);
+        grad[1 + 2 * i] = im_trace_slice<true>(x, z, ku);
+        rot_slice<true, false>(x, ku, c, -s);
+        rot_slice<true, true>(z, ku, c, s);
     }
     rec(0, c, s, kind);
     kind = rotc_ent<ROT>(kind);
     // here X = E S and Z = M^T A_m .. A_1.  dE/da = i |11><11| E  ->  dL/da = 2 Re(i (X Z)[3][3]) = -2 Im (X Z)[3][3]
-    // (S = 1: X[3][j] = e^{ia} delta_j3, i.e. -2 Im(e^{ia} Z[3][3]))
-    cx a33 = mk(0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < 4; j++) a33 = acc_swap<false>(a33, X[3][j], Z[j][3]);
+    // (S = 1: X[3][j] = e^{ia} delta_j3, i.e. -2 Im(e^{ia} Z[3][3])); slice j's term is X[3][j] Z[j][3]
+    const cx a33 = acc_swap<false>(mk(0.f, 0.f), x[3], z[3]);
     grad[0] = kind == K_CP ? -2.f * (re(a33) + im(a33)) : 0.f;
     if (fold_up || fold_dn) {
-        entangler_rows<true>(X, kind, c, s);              // X = S
-        entangler_cols(Z, kind, c, s);                    // Z = M^T A_m .. A_1 E
+        entangler_slice<true>(x, kind, c, s);             // X = S
+        entangler_slice<false>(z, kind, c, s);            // Z = M^T A_m .. A_1 E
         float cs, ss;
         if (fold_dn) for (int k = 2; k >= 0; k--) {
             surf(1, k, cs, ss);
-            gs_dn[k] = im_trace_sigma<false>(X, Z, surf_kind(k));
-            rot_rows<false>(X, surf_kind(k), cs, -ss);
-            rot_cols<false>(Z, surf_kind(k), cs, ss);
+            gs_dn[k] = im_trace_slice<false>(x, z, surf_kind(k));
+            rot_slice<false, false>(x, surf_kind(k), cs, -ss);
+            rot_slice<false, true>(z, surf_kind(k), cs, ss);
         }
         if (fold_up) for (int k = 2; k >= 0; k--) {
             surf(0, k, cs, ss);
-            gs_up[k] = im_trace_sigma<true>(X, Z, surf_kind(k));
-            rot_rows<true>(X, surf_kind(k), cs, -ss);
-            rot_cols<true>(Z, surf_kind(k), cs, ss);
+            gs_up[k] = im_trace_slice<true>(x, z, surf_kind(k));
+            rot_slice<true, false>(x, surf_kind(k), cs, -ss);
+            rot_slice<true, true>(z, surf_kind(k), cs, ss);
         }
     }
+}
+
+// ---- whole matrices (the CPU tests; the device takes the slices directly) ---------------------------------------------
+template <int ROT = 0, class Rec, class Surf = NoSurf>
+CPF_HD void block_matrix(cx (&G)[4][4], const Rec& rec, int n_rot, bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf()) {
+    for (int j = 0; j < 4; j++) {
+        cx x[4];
+        block_matrix_column<ROT>(x, j, rec, n_rot, fold_up, fold_dn, surf);
+        for (int i = 0; i < 4; i++) G[i][j] = x[i];
+    }
+}
+constexpr int MAX_BLOCK_ANGLES = 17;                      // 1 + 2 x 8 rotation letters
+template <int ROT = 0, class Rec, class Surf = NoSurf>
+CPF_HD void block_gradient(float* grad, const cx (&G)[4][4], const cx (&M)[4][4], const Rec& rec, int n_rot,
+                           bool fold_up = false, bool fold_dn = false, const Surf& surf = Surf(), float* gs_up = nullptr, float* gs_dn = nullptr) {
+    const int na = 1 + 2 * rotc_n<ROT>(n_rot);
+    for (int k = 0; k < na; k++) grad[k] = 0.f;
+    float su[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; j++) {
+        cx x[4], z[4];
+        for (int i = 0; i < 4; i++) { x[i] = G[i][j]; z[i] = M[i][j]; }        // Z[j][i] = M[i][j]
+        float g[MAX_BLOCK_ANGLES], pu[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
+        block_gradient_slice<ROT>(g, x, z, rec, n_rot, fold_up, fold_dn, surf, pu, pd);
+        for (int k = 0; k < na; k++) grad[k] += g[k];
+        for (int k = 0; k < 3; k++) { su[k] += pu[k]; sd[k] += pd[k]; }
+    }
+    if (fold_up) for (int k = 0; k < 3; k++) gs_up[k] = su[k];
+    if (fold_dn) for (int k = 0; k < 3; k++) gs_dn[k] = sd[k];
 }
 
 // When the placement's first qubit sits on the LOWER of the two register bits the kernel applies the block with the
