@@ -494,7 +494,8 @@ struct DenseLds {
 // surf_mask: qubits whose surface gate Rz Rx Rz the sweeps apply gate by gate; every other qubit's surface gate is folded
 // into the first block that touches it (cpf_dense_math.h; DenseBlock::z bits 9 / 10), which removes 3 x 18 rotations of
 // the full state per step (config 5: 6.4 % of the step, measured by leaving them out)
-// gmat: global scratch [samples][K][32 floats] for the block matrices of the scalar-register path (layer-specialised kernels)
+// gmat: global scratch [samples][K][32 floats] for the block matrices of the scalar-register path (layer-specialised kernels),
+// each matrix COLUMN-major ((re, im) of G_ij at float 2 (4 j + i)): the build phase's four column walkers write 32 contiguous bytes each
 struct DenseArgs { KArgs k; const DenseBlock* blocks; int K, n_rot, surf_mask; float* gmat; };
 #ifndef CPF_DENSE_SGPR
 #define CPF_DENSE_SGPR 1
@@ -609,7 +610,7 @@ __device__ __forceinline__ void dense_body(const DenseArgs& da) {
             for (int i = 0; i < 4; i++) {
                 const int ii = up_low ? dense::swap_bits2(i) : i;
                 out[4 * ii + jj] = make_float2(dense::re(x[i]), dense::im(x[i]));
-                if constexpr (SG) gout[4 * ii + jj] = make_float2(dense::re(x[i]), dense::im(x[i]));
+                if constexpr (SG) gout[4 * jj + ii] = make_float2(dense::re(x[i]), dense::im(x[i]));     // column-major: this lane's 32 contiguous bytes
             }
         }
         if constexpr (SG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the matrices have reached L2 ...
