@@ -227,10 +227,11 @@ def cmd_fix4(_args):
         print(env, eng.last_variant(), 'passed', len(passed), 'symmetric difference', sorted(passed ^ idx), 'cz same', same.mean(), flush=True)
 
 
-def cmd_stamps(_args):
-    eng, _ = engine('cfg2', T=500)
+def cmd_stamps(args):
+    cfg = args[0] if args else 'cfg2'
+    eng, Ss = engine(cfg, T=500)
     T = 500
-    out = eng.optimize(eng.initial_angles(0, int(os.environ.get('S', '1024'))), keep_history=True)
+    out = eng.optimize(eng.initial_angles(0, int(os.environ.get('S', str(Ss[0])))), keep_history=True)
     split = eng.last_variant().startswith('split')
     h = out['history_regloss'][0, :16].cpu().numpy().astype(np.float64)
     names = (['forward half', 'wait for other wave', 'loss/track', 'backward half', 'wait for other wave', 'owner', 'wait (owner)', 'loop top'] if split else
