@@ -222,6 +222,22 @@ def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
                                      same_flag_min=0.8)
 
 
+@pytest.mark.parametrize('name,variant,same_flag_min', [('raw_toff4_star_t14', 'layered/jit(hipcc) waves=4', 0.9), ('raw_4gt10_xz_t30', 'layered/jit(hipcc) waves=1', 0.98)])
+def test_stored_tutorial_and_paper_shapes_unbiased_against_float32_oracle(name, variant, same_flag_min, monkeypatch):
+    """The two remaining kernel variants the reference's stored trials exercise, at full length against the float32 oracle:
+    the four-waves-per-sample layout (4-qubit star of tutorial/results/toff4_star trial 14: 29 blocks, 500 samples - fewer
+    samples than SIMDs) and the one-wave kernel on an 'xz' template (5 qubits all-to-all, res_4gt10-v1_81 trial 30: 57 blocks,
+    2000 samples, where almost no run converges).  Kernels from the shipped cache."""
+    monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+
+    class Trial:
+        layer, num_cp_gates, target, rotation_gates = g['layer'].tolist(), int(g['num_cp_gates']), g['target'], str(g['rotation_gates'])
+        r, seed, num_gd_iterations = float(g['r']), int(g['seed']), 2000
+    Trial.name = name
+    _unbiased_against_float32_oracle(Trial, int(g['num_samples']), list(range(18, 40, 2)), 0.0, 2e-3, 2e-3, variant, same_flag_min=same_flag_min)
+
+
 @pytest.mark.parametrize('kernel', ['default', 'dense', 'gate-by-gate'])
 def test_config5_unbiased_against_float32_oracle(kernel, tune):
     """Config 5 (6 qubits, ring, 60 blocks, SU(64) target): 128 samples x 2000 iterations on the kernel the plan picks,
