@@ -80,6 +80,10 @@ __device__ __forceinline__ void reduce8_rows(const float (&d)[8], float* dst, in
 }
 
 __device__ __forceinline__ void load_rec(const float* p, float (&r)[16]) {
+#ifdef CPF_EXP_NORECLOAD          // timing experiment only (wrong results): what the per-block record reads cost
+    for (int i = 0; i < 16; i++) r[i] = 0.5f + 0.01f * i;
+    return;
+#endif
     const float4* q = reinterpret_cast<const float4*>(p);
     const float4 a = q[0], b = q[1], c = q[2], d = q[3];
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
