@@ -81,6 +81,12 @@ def precompile_shapes():
     # Ansatz(3, 'cz', fill_layers(connected_layer(3), k)).learn(...) with 1000 repeats (paper/results/local_minimums)
     conn3, chain3 = [[0, 1], [0, 2], [1, 2]], [[0, 1], [1, 2]]
     shapes += [(layer, 'xyz', K, 1000, 'cz') for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
+    # 3 qubits, the block counts an adaptive search over the reference's layers visits (tutorial/results/toff3_chain:
+    # 10..20): two-ended kernels specialised on the block count, which a launch picks up when it finds them (nothing
+    # compiles them at run time).  One per regime of samples per CU: one (<= 256 samples), a few with stored states
+    # (how many depends on K), saturated.  A few seconds of hipcc each.
+    shapes += [(layer, rot, K, S, 'cp', {'CPF_JIT_K': '1'}) for layer in (chain3, conn3) for rot in ('xyz', 'xz')
+               for K in range(6, 25) for S in (100, 512, 2048, 8192)]
     return shapes
 
 
@@ -103,18 +109,22 @@ def precompile(shapes=None, workers=None, verbose=True):
     shapes = precompile_shapes() if shapes is None else shapes
     env = dict(os.environ, CPF_JIT_CACHE=JIT_DIR)
 
-    def one(shape):
+    def batch(chunk):           # one process per few shapes (start-up costs as much as a cached look-up); a chunk shares its tuning
         code = ('import json, sys; from cpflow_amd.build import _precompile_one; '
-                'print(json.dumps(_precompile_one(*json.loads(sys.argv[1]))))')
-        r = subprocess.run([sys.executable, '-c', code, json.dumps(shape)], env=env, capture_output=True, text=True,
+                'print(json.dumps([_precompile_one(*s) for s in json.loads(sys.argv[1])]))')
+        r = subprocess.run([sys.executable, '-c', code, json.dumps(chunk)], env=env, capture_output=True, text=True,
                            cwd=os.path.dirname(HERE))
         if r.returncode:
-            raise RuntimeError(f'precompile of {shape} failed: {r.stderr[-400:]}')
+            raise RuntimeError(f'precompile of {chunk} failed: {r.stderr[-400:]}')
         return json.loads(r.stdout.strip().splitlines()[-1])
+    groups = {}
+    for shape in shapes:
+        groups.setdefault(json.dumps(shape[5] if len(shape) > 5 else None, sort_keys=True), []).append(shape)
+    chunks = [g[i:i + 4] for g in groups.values() for i in range(0, len(g), 4)]
     seen = set()
     with ThreadPoolExecutor(max_workers=workers or max(1, (os.cpu_count() or 2) - 1)) as ex:
-        for shape, lines in zip(shapes, ex.map(one, shapes)):
-            for line in lines:
+        for per_shape in ex.map(batch, chunks):
+            for line in (x for lines in per_shape for x in lines):
                 if verbose and line not in seen:
                     print(line)
                 seen.add(line)

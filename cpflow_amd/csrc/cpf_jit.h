@@ -136,7 +136,8 @@ struct Code { std::string bytes, backend, error, note, path; bool compiled = fal
 inline std::atomic<int>& compile_counter() { static std::atomic<int> n{0}; return n; }
 
 // Produce the code object of a spec without touching the GPU (cache look-ups, then a compile unless forbidden).
-inline Code build(const Spec& sp) {
+// cached_only: the look-ups alone; a miss is `error == "not cached"` and nothing is compiled or written.
+inline Code build(const Spec& sp, bool cached_only = false) {
     Code out;
     const std::string inc = lib_dir() + "/csrc";
     std::string hdrs;
@@ -179,6 +180,7 @@ inline Code build(const Spec& sp) {
             if (!out.bytes.empty()) { out.backend = backend; return out; }
         }
     }
+    if (cached_only) { out.error = "not cached"; return out; }
     if (forbid) { out.error = "run-time compile forbidden (CPF_JIT_FORBID_COMPILE=1) and no cached object for " + sp.body + dir_note; return out; }
     if (cdir.empty()) { out.error = "no writable private cache directory" + dir_note; return out; }
     out.note = dir_note;
@@ -234,14 +236,18 @@ struct Kernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; std::s
 inline std::map<std::string, Kernel>& table() { static std::map<std::string, Kernel> t; return t; }
 inline std::mutex& table_mutex() { static std::mutex m; return m; }
 
-// Returns the loaded kernel; fn == nullptr (with .error set) when it cannot be produced.
-inline const Kernel& get(int device, const Spec& sp) {
+// Returns the loaded kernel; fn == nullptr (with .error set) when it cannot be produced.  cached_only: never compile
+// (a kernel that is an optional upgrade over one the library already holds); its misses are remembered apart from the
+// failures of a full build, so that a later full build of the same body is still attempted.
+inline const Kernel& get(int device, const Spec& sp, bool cached_only = false) {
     const std::string key = "dev" + std::to_string(device) + ":" + sp.body;
     std::lock_guard<std::mutex> lock(table_mutex());
     auto it = table().find(key);
     if (it != table().end()) return it->second;
+    if (cached_only && (it = table().find("miss:" + key)) != table().end()) return it->second;
     Kernel k;
-    const Code code = build(sp);
+    const Code code = build(sp, cached_only);
+    if (cached_only && code.bytes.empty()) { k.error = code.error; return table()["miss:" + key] = k; }
     k.backend = code.backend;
     if (code.bytes.empty()) k.error = code.error;
     else if (hipModuleLoadData(&k.module, code.bytes.data()) != hipSuccess || hipModuleGetFunction(&k.fn, k.module, "cpf_jit_kernel") != hipSuccess) {

@@ -466,7 +466,9 @@ int ppt_bucket(int ppt) {          // angles per owner thread, rounded up to a f
     return ppt;
 }
 
-std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, int lw, int64_t S) {
+// k_mode: 0 = block count from the plan, 1 = one build per block count, -1 = as CPF_JIT_K says (opt-in);
+// only_split: the two-ended 3-qubit candidate alone.
+std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, int lw, int64_t S, int k_mode = -1, bool only_split = false) {
     std::vector<JitCandidate> out;
     plan->jit_note.clear();
     // CP blocks; CZ blocks as CP(pi) with a constant record slot; CX blocks as a row permutation in the gate-by-gate sweeps
@@ -481,17 +483,23 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
     cpf::KArgs a{};
     a.loss_kind = loss_kind;
     const char* jk = tuning("CPF_JIT_K");                                        // opt-in: one build per block count
-    const bool jit_k = jk && jk[0] == '1';
+    const bool jit_k = k_mode < 0 ? (jk && jk[0] == '1') : k_mode == 1;
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = ppt_bucket((P + 127) / 128);
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
-        const int smstore = (states_fit(plan, S, rot_code, slds2) ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
+        const bool states = states_fit(plan, S, rot_code, slds2);
+        int smstore = (states ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
+        // one sample per CU: the K-specialised kernel with the balanced cut (MSTORE bit 17, see launch_split3)
+        bool lone = jit_k && states && (S + plan->num_cu - 1) / plan->num_cu == 1;
+        { const char* e = tuning("CPF_PAIRS"); if (e) lone = lone && e[0] == '1'; }                   // A/B and tests: 0 = the saturated form
+        if (lone) smstore += 2 << 16;
         JitCandidate c;
-        c.lds = (smstore & 3) == 2 ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
+        c.lds = states ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
         c.spec = {"cpf_split.h", cpf_jit::body_expr("split_body", {rot_code, sppt, smstore}, plan->layer_ud), 128};
-        c.tag = std::string((smstore & 3) == 2 ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (smstore >> 2 ? " K" : "");
+        c.tag = std::string(states ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (jit_k ? " K" : "") + (lone ? " lone" : "");
         if (c.lds <= 64 * 1024) out.push_back(c);
     }
+    if (only_split) return out;
     int mstore = 0;
     if (plan->NQ == 3 && cpf::layered_merge(3, lw, rot_code)) {
         const size_t with = (size_t)cpf::LayeredLds<3>::total(plan->K, 1, true) * sizeof(float);
@@ -531,6 +539,34 @@ int precompile_landed(const cpf_jit::Code& code, const std::string& body) {
     return fail(-32, "precompile of %s: object written to %s, not under CPF_JIT_CACHE=%s%s", body.c_str(), code.path.c_str(), want, code.note.c_str());
 }
 
+int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const cpf_jit::Kernel& k, int64_t S, hipStream_t stream) {
+    cpf::KArgs args = a;
+    void* params[] = {&args};
+    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)c.spec.threads, 1, 1, (unsigned)c.lds, stream, params, nullptr);
+    plan->variant = tag_with_backend(c.tag, k.backend);
+    return e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+}
+
+// 3 qubits: a two-ended kernel specialised on the block count, when cpflow_amd/jit_cache/ (or the private cache) holds
+// one for this shape - python -m cpflow_amd.build --precompile ships them for the block counts an adaptive search over
+// the reference's 3-qubit layers visits.  Nothing is compiled here: a miss falls through to the kernels that read the
+// block count from the plan.  The tutorial's shape (chain_layer(3), 14 blocks, 100 samples): see DESIGN.md section 4.
+bool try_split3_cached_k(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || !kspec_enabled()) return false;
+    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: the plain runtime build
+    const int LL = (int)plan->layer_ud.size() / 2;
+    if (plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && ((LL == 2 && plan->K == 12) || (LL == 3 && plan->K == 16)) &&
+        (plan->layer_ud == std::vector<int>{0, 1, 1, 2} || plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2}))
+        return false;                      // built into the library (launch_layered3), with its two-samples-per-workgroup form
+    for (const JitCandidate& c : jit_candidates(plan, a.P, a.loss_kind, 0, S, 1, true)) {
+        const cpf_jit::Kernel& k = cpf_jit::get(plan->device, c.spec, true);
+        if (!k.fn) { if (k.error != "not cached") plan->jit_note = k.error; return false; }
+        *rc = launch_jit(plan, a, c, k, S, stream);
+        return true;
+    }
+    return false;
+}
+
 // lw = log2(waves per sample).  Returns true when a specialised kernel was launched (or a hard error is in *rc).
 bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE) return false;
@@ -541,11 +577,7 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
             if (k.error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", k.error.c_str()); return true; }
             continue;          // next candidate, then the generic kernel
         }
-        cpf::KArgs args = a;
-        void* params[] = {&args};
-        const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)c.spec.threads, 1, 1, (unsigned)c.lds, stream, params, nullptr);
-        plan->variant = tag_with_backend(c.tag, k.backend);
-        *rc = e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+        *rc = launch_jit(plan, a, c, k, S, stream);
         return true;
     }
     return false;
@@ -584,8 +616,9 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
         select_labelling(plan, which);
         apply_labelling(plan, which, a);
     }
-    // 1. ahead-of-time layered kernel (3 qubits, the reference's own layers); 2. runtime-specialised layered
-    // kernel; 3. generic per-gate kernel
+    // 0. a shipped 3-qubit kernel specialised on the block count; 1. ahead-of-time layered kernel (3 qubits, the
+    // reference's own layers); 2. runtime-specialised layered kernel; 3. generic per-gate kernel
+    if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_dense(plan, a, S, stream, &rc)) return rc;
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }

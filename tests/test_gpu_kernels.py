@@ -378,7 +378,7 @@ def test_two_qubit_problem_on_the_block_count_specialised_kernel(monkeypatch, tu
     tune.set('CPF_JIT_K', '1')
     eng = _engine(layer, K, target, rot, entangler='cz', num_gd_iterations=8, use_reg=False)
     out = eng.optimize(theta, keep_history=True)
-    assert eng.last_variant().startswith('split/jit') and eng.last_variant().endswith(' K'), eng.last_variant()
+    assert eng.last_variant().startswith('split/jit') and eng.last_variant().endswith(' K lone'), eng.last_variant()   # 3 samples: one per CU
     assert np.abs(out['history_regloss'].cpu().numpy() - ref['history_loss']).max() < 2e-5
 
 
@@ -488,6 +488,50 @@ def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, m
     hp = eng.optimize(init, frozen=frozen, keep_history=True)['history_params'].cpu().numpy()
     assert (hp[:, :, ::3] == init[:, None, ::3]).all() and (hp[S // 2:, :, 1] == init[S // 2:, None, 1]).all()
     assert (hp[:, -1, 2::3] != init[:, 2::3]).any()
+
+
+@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 14, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 19, 'xyz'), ([[0, 1], [1, 2]], 9, 'xz')])
+@pytest.mark.parametrize('knobs,S,variant', [({}, 5, 'split/jit(hipcc) waves=2 states K lone'), ({'CPF_PAIRS': '0'}, 6, 'split/jit(hipcc) waves=2 states K'),
+                                             ({'CPF_PSTORE': '0'}, 7, 'split/jit(hipcc) waves=2 K')])
+def test_shipped_block_count_specialised_kernels(layer, K, rot, knobs, S, variant, monkeypatch, tune):
+    """3 qubits, block counts other than the BASELINE ones (an adaptive search over chain_layer(3) / connected_layer(3),
+    tutorial/results/toff3_chain): the launch picks up the K-specialised two-ended kernels that
+    `python -m cpflow_amd.build --precompile` shipped - one per regime of samples per CU - and compiles nothing; a block
+    count nobody shipped runs on the kernel that reads K from the plan, with compilation still forbidden.  Each form
+    against the float64 oracle (history, penalty, frozen mask)."""
+    from cpflow_amd import _ffi
+    monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
+    for k, v in knobs.items():
+        tune.set(k, v)
+    target = _rand_unitary(3, 43)
+    T = 14
+    before = _ffi.lib().cpf_jit_compiles()
+    orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
+    eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
+    init = orc.initial_angles(3, S)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant() == variant, eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6
+    err = np.abs(out['history_regloss'] - ref['history_loss'])
+    assert np.median(err[:, :10].max(axis=1)) < 1e-5 and np.median(err.max(axis=1)) < 3e-5 and err.max() < 5e-4
+    assert np.abs(out['history_params'] - ref['history_params'])[:, :3].max() < 1e-4
+    assert (out['params'][:, 0] == init).all() and (out['cz'] == ref['cz']).all() and (out['passed'] == ref['passed']).all()
+    assert np.median(np.abs(out['loss'] - ref['loss'])) < 2e-5 and np.abs(out['reg'][:, 0] - ref['reg'][:, 0]).max() < 1e-6
+    frozen = np.zeros((S, orc.P), np.uint8)
+    frozen[:, ::3] = 1
+    hp = eng.optimize(init, frozen=frozen, keep_history=True)['history_params'].cpu().numpy()
+    assert eng.last_variant() == variant
+    assert (hp[:, :, ::3] == init[:, None, ::3]).all() and (hp[:, -1, 1::3] != init[:, 1::3]).any()
+    # not shipped: 27 blocks; and with the K-specialised kernels switched off
+    eng = _engine(layer, 27, target, rot, num_gd_iterations=3)
+    eng.optimize(eng.initial_angles(1, S))
+    assert eng.last_variant().startswith('split/') and ' K' not in eng.last_variant(), eng.last_variant()
+    tune.set('CPF_KSPEC', '0')
+    eng = _engine(layer, K, target, rot, num_gd_iterations=3)
+    eng.optimize(eng.initial_angles(1, S))
+    assert eng.last_variant().startswith('split/') and ' K' not in eng.last_variant(), eng.last_variant()
+    assert _ffi.lib().cpf_jit_compiles() == before
 
 
 def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch, tune):

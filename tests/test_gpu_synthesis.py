@@ -40,6 +40,8 @@ def test_T3_golden_end_of_run(name, min_same):
     eng = _engine(g['layer'], int(g['num_cp_gates']), g['target'], str(g['rotation_gates']), r=float(g['r']))
     init = eng.initial_angles(int(g['seed']), S)
     out = _np(eng.optimize(init))
+    if 'toff3' in name:      # 14 / 15 blocks, 100 samples: the shipped K-specialised two-ended kernel, one sample per CU
+        assert eng.last_variant() == 'split/jit(hipcc) waves=2 states K lone', eng.last_variant()
     idx = g['sample_index']
     assert (out['params'][idx, 0].view(np.uint32) == g['params'][:, 0].view(np.uint32)).all()   # T0
     passed = set(np.flatnonzero(out['passed']))
@@ -388,7 +390,7 @@ def _score(cz_passed, S):
 T3_MORE = [
     # G3, 3 qubits all-to-all, 200 samples: 198 stored; float32 / float64 oracle: 199 passes, all 198 stored ones among them.
     # Its stored reg values come from older penalty constants, which moves a few CZ counts, not the pass set
-    ('raw_toff3_conn_t99', 'split/', 3, 195, 14, 0.15),
+    ('raw_toff3_conn_t99', 'split/jit(hipcc) waves=2 states K lone', 3, 195, 14, 0.15),      # 10 blocks: a shipped K-specialised kernel
     # G2 trial 49, 4-qubit star, 500 samples, 7 stored passes (the oracle finds the same 7)
     ('raw_toff4_star_t49', 'layered/jit(hipcc)', 4, 5, 4, 1.6),
     # G5, 5-qubit chain 'xyz', 86 blocks, 1000 samples, 39 stored passes.  The stored run used OLDER penalty constants (its

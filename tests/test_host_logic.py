@@ -212,6 +212,32 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
 
 
+def test_block_count_specialised_kernels_per_regime():
+    """3 qubits: the K-specialised two-ended kernel a launch would look up, by samples per CU (cpflow_amd.hip
+    jit_candidates with k_mode 1; MSTORE = form + 4 K + the balanced-cut bit 17): one sample per CU -> stored states and the
+    balanced cut, a few per CU -> stored states, saturated -> un-apply.  All three are in the shipped cache for the block
+    counts of an adaptive search (build.precompile_shapes), so FORBID_COMPILE does not bite."""
+    import json
+    import subprocess
+    import sys
+    chain3 = [[0, 1], [1, 2]]
+
+    def kernels(K, S):
+        code = ("import json, sys; from cpflow_amd.build import _precompile_one; "
+                f"print(json.dumps(_precompile_one({chain3!r}, 'xyz', {K}, {S}, tuning={{'CPF_JIT_K': '1'}})))")
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CPF_JIT_FORBID_COMPILE='1'), capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout.strip().splitlines()[-1])[0]
+    assert kernels(14, 100).startswith(f'split/jit(hipcc) waves=2 states K lone [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (2 << 16)}, 0, 1, 1, 2>')
+    assert kernels(14, 512).startswith(f'split/jit(hipcc) waves=2 states K [cached] cpf::split_body<8451, 1, {2 + 4 * 14}, 0, 1, 1, 2>')
+    assert kernels(14, 8192).startswith(f'split/jit(hipcc) waves=2 K [cached] cpf::split_body<8451, 1, {1 + 4 * 14}, 0, 1, 1, 2>')
+    assert kernels(20, 100).startswith('split/jit(hipcc) waves=2 states K lone [cached]')
+    assert kernels(24, 100).startswith('split/jit(hipcc) waves=2 K [cached]')              # stored states above 64 KB of LDS: not built
+    from cpflow_amd.build import precompile_shapes
+    ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
+    assert {s[2] for s in ks} == set(range(6, 25)) and {s[3] for s in ks} == {100, 512, 2048, 8192}
+
+
 def test_qubit_relabelling_of_the_plan_shape(tmp_path):
     """fill_plan_shape (cpflow_amd.hip): with one wave per sample the 4- / 5-qubit kernels are built around the layer
     with the most-used qubits last (the register qubits); four-wave launches and symmetric layers keep the problem's own

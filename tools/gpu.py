@@ -41,6 +41,8 @@ def configs():
     c['n4star'] = ([[0, 1], [0, 2], [0, 3]], 23, rand_u(4, 1), [500])
     c['n5k86'] = ([[0, 1], [1, 2], [2, 3], [3, 4]], 86, rand_u(5, 2), [1000])          # the shape of paper/results/benchmarks/res_4gt13_91
     c['n5conn'] = ([[i, j] for i in range(5) for j in range(i + 1, 5)], 57, rand_u(5, 3), [2000])   # ... res_4gt10-v1_81 ('xz' there)
+    c['n3k14'] = ([[0, 1], [1, 2]], 14, rand_u(3, 4), [100])                            # the adaptive tutorial's shape (toff3_chain)
+    c['n3c18'] = ([[0, 1], [0, 2], [1, 2]], 18, rand_u(3, 5), [100])
     return c
 
 
