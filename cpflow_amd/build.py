@@ -87,6 +87,8 @@ def precompile_shapes():
     # (how many depends on K), saturated.  A few seconds of hipcc each.
     shapes += [(layer, rot, K, S, 'cp', {'CPF_JIT_K': '1'}) for layer in (chain3, conn3) for rot in ('xyz', 'xz')
                for K in range(6, 25) for S in (100, 512, 2048, 8192)]
+    # ... and the 'cz' template runs above (1000 starts: a few samples per CU)
+    shapes += [(layer, 'xyz', K, 1000, 'cz', {'CPF_JIT_K': '1'}) for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     return shapes
 
 

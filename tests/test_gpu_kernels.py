@@ -272,7 +272,9 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
 
 
 @pytest.mark.parametrize('ent,layer,K,rot,S,kind', [
-    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'split/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'layered/jit'),
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'split/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'split/jit(hipcc) waves=2 K'),
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'split/jit(hipcc) waves=2 states K'),       # the local-minimum study's shape: shipped K-specialised
+    ('cz', [[0, 1], [0, 2], [1, 2]], 15, 'xyz', 3000, 'layered/jit'),                            # a block count nobody shipped, SIMDs full: one wave per sample
     ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'layered/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'split/jit'),
     ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'layered/jit'),
     ('cx', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'layered/jit'), ('cx', [[2, 1], [0, 2]], 7, 'zy', 1500, 'layered/jit'),

@@ -235,7 +235,8 @@ def test_block_count_specialised_kernels_per_regime():
     assert kernels(24, 100).startswith('split/jit(hipcc) waves=2 K [cached]')              # stored states above 64 KB of LDS: not built
     from cpflow_amd.build import precompile_shapes
     ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
-    assert {s[2] for s in ks} == set(range(6, 25)) and {s[3] for s in ks} == {100, 512, 2048, 8192}
+    assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 512, 2048, 8192}
+    assert {(s[2], s[3]) for s in ks if s[4] == 'cz'} == {(K, 1000) for K in range(2, 17, 2)}        # the 'cz' template study
 
 
 def test_qubit_relabelling_of_the_plan_shape(tmp_path):

@@ -42,6 +42,7 @@ def configs():
     c['n5k86'] = ([[0, 1], [1, 2], [2, 3], [3, 4]], 86, rand_u(5, 2), [1000])          # the shape of paper/results/benchmarks/res_4gt13_91
     c['n5conn'] = ([[i, j] for i in range(5) for j in range(i + 1, 5)], 57, rand_u(5, 3), [2000])   # ... res_4gt10-v1_81 ('xz' there)
     c['n3k14'] = ([[0, 1], [1, 2]], 14, rand_u(3, 4), [100])                            # the adaptive tutorial's shape (toff3_chain)
+    c['n3cz8'] = ([[0, 1], [0, 2], [1, 2]], 8, rand_u(3, 6), [1000])                     # paper/results/local_minimums: Ansatz(3, 'cz', ...)
     c['n3c18'] = ([[0, 1], [0, 2], [1, 2]], 18, rand_u(3, 5), [100])
     return c
 
@@ -62,6 +63,8 @@ def engine(cfg, T=None, **kw):
     from cpflow_amd.engine import TemplateEngine
     sync_tuning()
     layer, K, tgt, Ss = configs()[cfg]
+    if cfg == 'n3cz8':
+        kw.setdefault('entangler', 'cz')
     return TemplateEngine(layer, K, tgt, kw.pop('rot', 'xyz'), num_gd_iterations=int(os.environ.get('T', '2000')) if T is None else T, **kw), Ss
 
 
