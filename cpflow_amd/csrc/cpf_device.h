@@ -141,6 +141,9 @@ __device__ __forceinline__ float dppz(float x) {
 // value held by lane (lane ^ (1 << BIT))
 template <int BIT>
 __device__ __forceinline__ float xor_lane(float x) {
+#ifdef CPF_EXP_SWZ          // A/B build: the partner over the LDS crossbar (ds_swizzle_b32, bit-mask mode) instead of DPP
+    if constexpr (BIT < 5) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), ((1 << BIT) << 10) | 0x1f));
+#endif
     if constexpr (BIT == 0) return dppz<0xB1>(x);            // quad_perm:[1,0,3,2]
     else if constexpr (BIT == 1) return dppz<0x4E>(x);       // quad_perm:[2,3,0,1]
     else if constexpr (BIT == 3) return dppz<0x128>(x);      // row_ror:8
