@@ -207,9 +207,28 @@ struct State {
 
 // ---- rotations: forward / inverse application to one matrix
 // s is sin(a/2) for the forward gate, -sin(a/2) for the inverse.
+// SH (register qubits, x / y rotations; the layered kernels' blocks): the rotation as three shears (lifting steps)
+//     a += u b,  b += v a,  a += u b      with u = -i t (x) or -t (y), v = -i s (x) or +s (y), t = tan(a/4) = s / (1 + c):
+// [[1, u], [0, 1]] [[1, 0], [v, 1]] [[1, u], [0, 1]] = [[1 + uv, u (2 + uv)], [v, 1 + uv]] = [[c, -i s], [-i s, c]] (x: uv = -ts = c - 1,
+// t (1 + c) = s) - three packed FMAs per amplitude pair instead of two multiplies and two FMAs.  The caller passes (t, s) for the
+// gate and (-t, -s) for its inverse (which is then the exact inverse of what the forward sweep applied); the owner phase
+// publishes t in the record's cosine slot, after taking the angle into |a/2| <= pi / 2 at the price of a global sign that no
+// loss sees (shear_record below), so |t| <= tan(pi / 4) = 1 and the steps are as well conditioned as the rotation.
+#ifndef CPF_SHEAR
+#define CPF_SHEAR 1          // A/B: 0 = two multiplies + two FMAs per pair everywhere
+#endif
 template <class L, int KIND, int Q>
+__host__ __device__ constexpr bool shear_gate() { return CPF_SHEAR != 0 && KIND != OP_RZ && !L::row_on_lane(Q); }
+// (cos, sin) of a gate's half angle -> what a shear gate's record holds: (tan of the quarter angle, sin), signs as above
+__device__ __forceinline__ void shear_record(float& c, float& s) {
+    const float sg = c < 0.f ? -1.f : 1.f;
+    s *= sg;
+    c = s * __frcp_rn(1.f + sg * c);
+}
+template <class L, int KIND, int Q, bool SH = false>
 __device__ __forceinline__ void rot_apply(f2 (&x)[L::E], float c, float s, const State<L>& st) {
     constexpr int BIT = L::row_bit(Q);
+    static_assert(!SH || (KIND != OP_RZ && !L::row_on_lane(Q)), "shear form: x / y rotations on register qubits");
     if constexpr (L::row_on_lane(Q)) {
         const float ss = st.sg[Q] * s;
 #pragma unroll
@@ -236,6 +255,20 @@ __device__ __forceinline__ void rot_apply(f2 (&x)[L::E], float c, float s, const
             if (e0 & (1 << BIT)) continue;
             const int e1 = e0 | (1 << BIT);
             const f2 a = x[e0], b = x[e1];
+            if constexpr (SH) {                       // c holds t
+                if constexpr (KIND == OP_RX) {
+                    const f2 a1 = pk_fma(f2{c, -c}, swp(b), a);
+                    const f2 b1 = pk_fma(f2{s, -s}, swp(a1), b);
+                    x[e0] = pk_fma(f2{c, -c}, swp(b1), a1);
+                    x[e1] = b1;
+                } else {
+                    const f2 a1 = pk_fma(splat(-c), b, a);
+                    const f2 b1 = pk_fma(splat(s), a1, b);
+                    x[e0] = pk_fma(splat(-c), b1, a1);
+                    x[e1] = b1;
+                }
+                continue;
+            }
             if constexpr (KIND == OP_RX) {            // a' = c a - i s b, b' = c b - i s a
                 x[e0] = pk_fma(f2{s, -s}, swp(b), splat(c) * a);
                 x[e1] = pk_fma(f2{s, -s}, swp(a), splat(c) * b);

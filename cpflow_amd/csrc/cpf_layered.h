@@ -60,7 +60,7 @@ struct LayeredLds {                                       // float offsets; [0, 
     }
 };
 
-template <class L, int KIND, int Q>
+template <class L, int KIND, int Q, bool SH = false>
 __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s);
 template <class L>
 __device__ __forceinline__ void gate_fence();
@@ -91,9 +91,9 @@ __device__ __forceinline__ void lay_block_fwd_inner(State<L>& st, const float (&
 #pragma unroll
     for (int i = 0; i < NR - 1; i++) {
         if (rot_kind(ROT, i) == OP_RX) {
-            rot_apply<L, OP_RX, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RX, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
+            rot_apply<L, OP_RX, UP, shear_gate<L, OP_RX, UP>()>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RX, DN, shear_gate<L, OP_RX, DN>()>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         } else if (rot_kind(ROT, i) == OP_RY) {
-            rot_apply<L, OP_RY, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RY, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
+            rot_apply<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         } else {
             rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], r[4 * i + 1], st); rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st);
         }
@@ -105,9 +105,9 @@ __device__ __forceinline__ void lay_block_bwd_inner(State<L>& st, const float (&
 #pragma unroll
     for (int i = NR - 2; i >= 0; i--) {
         if (rot_kind(ROT, i) == OP_RX) {
-            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP>(st, r[4 * i], r[4 * i + 1]);
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN, shear_gate<L, OP_RX, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP, shear_gate<L, OP_RX, UP>()>(st, r[4 * i], r[4 * i + 1]);
         } else if (rot_kind(ROT, i) == OP_RY) {
-            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP>(st, r[4 * i], r[4 * i + 1]);
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st, r[4 * i], r[4 * i + 1]);
         } else {
             d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
         }
@@ -133,11 +133,11 @@ __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         if (rot_kind(ROT, i) == OP_RX) {
-            rot_apply<L, OP_RX, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
-            rot_apply<L, OP_RX, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+            rot_apply<L, OP_RX, UP, shear_gate<L, OP_RX, UP>()>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RX, DN, shear_gate<L, OP_RX, DN>()>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
         } else if (rot_kind(ROT, i) == OP_RY) {
-            rot_apply<L, OP_RY, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
-            rot_apply<L, OP_RY, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+            rot_apply<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
+            rot_apply<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
         } else {
             rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
             rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
@@ -151,14 +151,17 @@ __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]
 // Only there: for a register qubit (and with one element per lane) reading the gradient first keeps it off the
 // un-application's dependency chain, which matters when a SIMD holds a single wave (5-qubit chain at 1000 samples: 141 ms
 // against 148 with the late read everywhere).
-template <class L, int KIND, int Q>
+// SH: a block's x / y rotation on a register qubit, whose record holds (t, s) - the inverse is (-t, -s); the surface gates'
+// records hold (cos, sin) whatever the qubit
+template <class L, int KIND, int Q, bool SH>
 __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s) {
     constexpr bool LATE = L::row_on_lane(Q) && L::E > 1 && KIND != OP_RZ;
+    static_assert(!SH || shear_gate<L, KIND, Q>(), "shear form: a block's x / y rotation on a register qubit");
     float d = 0.f;
     if constexpr (!LATE) { d = rot_grad<L, KIND, Q>(st); gate_fence<L>(); }
-    rot_apply<L, KIND, Q>(st.p, c, -s, st);
+    rot_apply<L, KIND, Q, SH>(st.p, SH ? -c : c, -s, st);
     gate_fence<L>();
-    rot_apply<L, KIND, Q>(st.c, c, -s, st);
+    rot_apply<L, KIND, Q, SH>(st.c, SH ? -c : c, -s, st);
     gate_fence<L>();
     if constexpr (LATE) { d = rot_grad<L, KIND, Q>(st); gate_fence<L>(); }
     return d;
@@ -172,9 +175,9 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
 #pragma unroll
     for (int i = NR - 1; i >= 0; i--) {
         if (rot_kind(ROT, i) == OP_RX) {
-            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP>(st, r[4 * i], r[4 * i + 1]);
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN, shear_gate<L, OP_RX, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP, shear_gate<L, OP_RX, UP>()>(st, r[4 * i], r[4 * i + 1]);
         } else if (rot_kind(ROT, i) == OP_RY) {
-            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP>(st, r[4 * i], r[4 * i + 1]);
+            d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st, r[4 * i], r[4 * i + 1]);
         } else {
             d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
         }
@@ -266,12 +269,13 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     // ---- owner state.  Owner slot o = tid + THREADS * s; the K CP angles come first.
     float th[PPT], mm[PPT], vv[PPT], psl[PPT], pval[PPT];
     int cs_off[PPT], g_off[PPT], pj[PPT];
-    bool valid[PPT], is_cp[PPT], frz[PPT];
+    bool valid[PPT], is_cp[PPT], frz[PPT], shr[PPT];
     penalty_table_init(smem, a, tid);
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
         const int o = tid + THREADS * s;
         valid[s] = o < P;
+        shr[s] = false;
         int j = 0;
         if (valid[s]) {
             if constexpr (ENT != 0) j = o;                       // no CP angles: slots in parameter order
@@ -289,6 +293,8 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         else {
             const int b = (j - NSP) / NBP, k = (j - NSP) % NBP;
             cs_off[s] = Lds::BLK_CS + 16 * b + 2 * k; g_off[s] = 32 * Lds::NBATCH + 32 * b + 4 * k;
+            // x / y rotation on a register qubit: its record holds (t, s) (cpf_device.h rot_apply, SH)
+            if (valid[s] && k < 2 * NR && rot_kind(ROT, k >> 1) != OP_RZ) shr[s] = CPF_SHEAR != 0 && !L::row_on_lane(PL::v[2 * (b % LL) + (k & 1)]);
         }
         th[s] = valid[s] ? init[j] : 0.f;
         mm[s] = 0.f; vv[s] = 0.f; psl[s] = 0.f; pval[s] = 0.f;
@@ -308,6 +314,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
         if (lin) { x = floor_mod_2pi(th[s]); si = penalty_lookup(smem, x); }
         float sn, cn;
         fast_sincos(is_cp[s] ? th[s] : 0.5f * th[s], sn, cn);       // 3.4 % of config 2's kernel time
+        if constexpr (L::E > 1) { if (shr[s]) shear_record(cn, sn); }
         if (valid[s]) *reinterpret_cast<float2*>(smem + cs_off[s]) = make_float2(cn, sn);
         if (lin) { pval[s] = __fadd_rn(__fmul_rn(si.x, x), si.y); psl[s] = a.r * si.x; }
         else if (pen) { float sl; pval[s] = penalty_lds(smem, a.pen_kind, th[s], sl); psl[s] = a.r * sl; }

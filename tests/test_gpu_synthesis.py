@@ -168,9 +168,11 @@ def test_full_size_properties(cfg):
     bi = out['regloss'].argmin(1)
     lbest = np.take_along_axis(out['loss'], bi[:, None], 1)[:, 0]
     assert (out['passed'] == (lbest <= np.float32(1e-3))).all()
-    # re-evaluating the stored best angles reproduces the stored best regloss (same kernel arithmetic)
+    # re-evaluating the stored best angles reproduces the stored best regloss (another kernel: the generic one applies every
+    # rotation as cos / sin products, the optimiser's register-qubit rotations are three shears - cpf_device.h rot_apply, SH;
+    # 168 gates of float32 rounding apart: 1.3e-6 at most over config 4's 2048 samples)
     re = _np(eng.loss_and_grad(out['params'][:, 1], with_grad=False))
-    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < 1e-6
+    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < 3e-6
     # CZ count recomputed on the host from the best angles
     cp = out['params'][np.arange(S), bi][:, eng.cp_mask == 1] % np.float32(2 * np.pi)
     v = np.full(cp.shape, 2)
