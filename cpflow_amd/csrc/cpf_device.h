@@ -283,6 +283,40 @@ __device__ __forceinline__ void rot_apply(f2 (&x)[L::E], float c, float s, const
     }
 }
 
+// ---- a block's Rz(up) (x) Rz(dn) as ONE complex multiply per amplitude (more than one amplitude per lane).
+// Rz(a) multiplies an amplitude by cos(a/2) + i sigma sin(a/2), sigma = +1 / -1 with the qubit's bit set / clear, so the pair is
+// (cu cd - su sd sigma_u sigma_d) + i (sigma_u su cd + sigma_d cu sd): four phases, two of them the conjugates of the other two -
+// six scalar operations per block and sweep, then two packed instructions per amplitude instead of four.  A lane qubit's sigma
+// is the lane's sign (folded into its sine), a register qubit's the bit of the amplitude index.  Inverse: both sines negated.
+#ifndef CPF_RZPAIR
+#define CPF_RZPAIR 1         // A/B: 0 = two separate Rz applications
+#endif
+template <class L, int UP, int DN>
+struct RzPair {
+    float ar, ai, br, bi;        // sigma_u = sigma_d = +1: (ar, ai);  sigma_u = -1, sigma_d = +1: (br, bi);  the others: conjugates
+    __device__ __forceinline__ RzPair(float cu, float su, float cd, float sd, const State<L>& st) {
+        float Su = su, Sd = sd;
+        if constexpr (L::row_on_lane(UP)) Su *= st.sg[UP];
+        if constexpr (L::row_on_lane(DN)) Sd *= st.sg[DN];
+        const float p = cu * cd, t = cu * Sd;
+        ar = fmaf(-Su, Sd, p); br = fmaf(Su, Sd, p);
+        ai = fmaf(Su, cd, t);  bi = fmaf(-Su, cd, t);
+    }
+    __device__ __forceinline__ void apply(f2 (&x)[L::E]) const {
+#pragma unroll
+        for (int e = 0; e < L::E; e++) {
+            const bool pu = L::row_on_lane(UP) || ((e >> L::row_bit(UP)) & 1), pd = L::row_on_lane(DN) || ((e >> L::row_bit(DN)) & 1);
+            if (pu == pd) {
+                if (pu) x[e] = pk_fma(f2{-ai, ai}, swp(x[e]), splat(ar) * x[e]);
+                else x[e] = pk_fma(f2{ai, -ai}, swp(x[e]), splat(ar) * x[e]);
+            } else {
+                if (pd) x[e] = pk_fma(f2{-bi, bi}, swp(x[e]), splat(br) * x[e]);
+                else x[e] = pk_fma(f2{bi, -bi}, swp(x[e]), splat(br) * x[e]);
+            }
+        }
+    }
+};
+
 // ---- rotations: derivative contribution, evaluated with psi, C right after the gate.
 // Returns this thread's share of  sum Im(conj(C) sigma psi)   (C carries the factor 1/2).
 template <class L, int KIND, int Q>

@@ -138,6 +138,9 @@ __device__ __forceinline__ void lay_block_fwd(State<L>& st, const float (&r)[16]
         } else if (rot_kind(ROT, i) == OP_RY) {
             rot_apply<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
             rot_apply<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
+        } else if constexpr (L::E > 1 && CPF_RZPAIR != 0) {
+            const RzPair<L, UP, DN> z(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3], st);
+            z.apply(st.p); gate_fence<L>();
         } else {
             rot_apply<L, OP_RZ, UP>(st.p, r[4 * i], r[4 * i + 1], st); gate_fence<L>();
             rot_apply<L, OP_RZ, DN>(st.p, r[4 * i + 2], r[4 * i + 3], st); gate_fence<L>();
@@ -178,6 +181,12 @@ __device__ __forceinline__ void lay_block_bwd(State<L>& st, const float (&r)[16]
             d[2 * i + 1] = lay_rot_bwd<L, OP_RX, DN, shear_gate<L, OP_RX, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RX, UP, shear_gate<L, OP_RX, UP>()>(st, r[4 * i], r[4 * i + 1]);
         } else if (rot_kind(ROT, i) == OP_RY) {
             d[2 * i + 1] = lay_rot_bwd<L, OP_RY, DN, shear_gate<L, OP_RY, DN>()>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RY, UP, shear_gate<L, OP_RY, UP>()>(st, r[4 * i], r[4 * i + 1]);
+        } else if constexpr (L::E > 1 && CPF_RZPAIR != 0) {
+            // both gradients before the pair is un-applied (conj(C) sigma_z psi does not change under a diagonal gate on psi and C)
+            d[2 * i + 1] = rot_grad<L, OP_RZ, DN>(st); d[2 * i] = rot_grad<L, OP_RZ, UP>(st); gate_fence<L>();
+            const RzPair<L, UP, DN> z(r[4 * i], -r[4 * i + 1], r[4 * i + 2], -r[4 * i + 3], st);
+            z.apply(st.p); gate_fence<L>();
+            z.apply(st.c); gate_fence<L>();
         } else {
             d[2 * i + 1] = lay_rot_bwd<L, OP_RZ, DN>(st, r[4 * i + 2], r[4 * i + 3]); d[2 * i] = lay_rot_bwd<L, OP_RZ, UP>(st, r[4 * i], r[4 * i + 1]);
         }
