@@ -80,6 +80,7 @@ struct KArgs {
     int prio;                  // two-ended kernel: raise the longer wave's issue priority (launches that leave SIMDs unsaturated)
     int nsamples;              // samples of this launch (kernels with several samples per workgroup mask the tail)
     int lone;                  // two-ended kernel, K from the plan: at most one sample per CU - balance the two waves' chains
+    int group;                 // one-wave layered kernels: samples per workgroup (0 / 1: one; cpf_layered.h layered_body)
 };
 
 // ------------------------------------------------------------------ layout

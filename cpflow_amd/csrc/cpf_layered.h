@@ -244,14 +244,21 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
     // MSTORE = 0: the backward pass rebuilds it (12 more ops per block, no LDS: better once LDS limits occupancy)
     constexpr bool STORE = MERGE && (MSTORE != 0);
     static_assert(LL >= 1 && NR >= 1 && NR <= 3, "layered kernel: 1..3 rotation letters, non-empty layer");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+    // One wave per sample: a workgroup may hold several samples (KArgs::group), one per wave, each with its own copy of the LDS
+    // map - the waves never meet (lds_sync<1> is no hardware barrier).  The dispatcher puts the waves of ONE workgroup on the
+    // CU's four SIMDs in turn, which single-wave workgroups are not guaranteed: 1000 of them on 1024 SIMDs left SIMDs with
+    // two waves and others empty in some launches (5-qubit chain, 36 blocks, 1000 samples: 118 or 190 ms from run to run).
+    const int sub = L::WPS == 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+    const int tid = L::WPS == 1 ? ((int)threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63;
+    const int wave = L::WPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     // NSP: surface PARAMETERS.  A 2-qubit problem runs as U (x) I on the 3-qubit kernel: the spectator's three surface
     // record slots hold the identity (cos, sin) = (1, 0) and belong to no parameter.
     const int NSP = 3 * a.n_actual;
     const int P = a.P, K = (P - NSP) / NBP;
-    const int64_t s_idx = blockIdx.x;
+    const int64_t s_idx = (int64_t)blockIdx.x * (a.group > 1 && L::WPS == 1 ? a.group : 1) + sub;
+    if (L::WPS == 1 && s_idx >= a.nsamples) return;
+    float* smem = smem_wg + sub * Lds::total(K, WPS, STORE);
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
@@ -641,7 +648,7 @@ __device__ __forceinline__ void layered_body(const KArgs& a) {
 }
 
 template <int NQ, int LW, int ROT, int PPT, int MSTORE, int... UD>
-__global__ __launch_bounds__(64 << LW, 1) void k_cp_layered(const KArgs a) {
+__global__ __launch_bounds__(LW == 0 ? 256 : 64 << LW, 1) void k_cp_layered(const KArgs a) {
     layered_body<NQ, LW, ROT, PPT, MSTORE, UD...>(a);
 }
 

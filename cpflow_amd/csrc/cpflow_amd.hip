@@ -298,11 +298,26 @@ bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipS
 // Ahead-of-time instances for the two larger BASELINE configurations, so that they do not depend on a compiler
 // being present at run time: 4 qubits chain_layer(4) (config 4: K = 24, 180 angles, 1 wave) and 6 qubits on a
 // ring (config 5: K = 60, 438 angles, 4 waves).
+// One-wave layered kernels of 4 and more qubits: samples per workgroup (cpf_layered.h layered_body, KArgs::group).  Four waves of
+// one workgroup land on the CU's four SIMDs, so a launch of up to 1024 samples runs one wave per SIMD and one of 2048 two, whatever
+// the dispatcher would have done with single-wave workgroups (same box, 4-qubit star, 23 blocks: 800 / 900 samples 43 ms as
+// single-wave workgroups, 26 ms grouped; 5-qubit chain, 36 blocks, 1000 samples: 118 or 190 ms from run to run, 118 grouped).
+int layered_group(const cpf_plan* plan, int lw, int64_t S, size_t lds_per_sample) {
+    int g = 1;
+    // not for launches that fill every SIMD twice anyway (config 4, 2048 samples: 45.6 ms single, 45.8 grouped)
+    if (lw == 0 && plan->NQ >= 4 && S > plan->num_cu && S < 8 * (int64_t)plan->num_cu) g = 4 * lds_per_sample <= 64 * 1024 ? 4 : (2 * lds_per_sample <= 64 * 1024 ? 2 : 1);
+    { const char* e = tuning("CPF_GROUP"); if (e && lw == 0 && plan->NQ >= 4) g = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1); }      // A/B and tests
+    while (g > 1 && (size_t)g * lds_per_sample > 64 * 1024) g >>= 1;
+    return g;
+}
 template <int NQ, int LW, int ROT, int PPT, int... UD>
-int launch_layered_aot(const cpf::KArgs& a, int K, int64_t S, hipStream_t stream) {
+int launch_layered_aot(const cpf_plan* plan, const cpf::KArgs& a_in, int K, int64_t S, hipStream_t stream) {
     const size_t lds = (size_t)cpf::LayeredLds<NQ>::total(K, 1 << LW, false) * sizeof(float);
     if (lds > 64 * 1024) return fail(-20, "LDS footprint above 64 KiB");
-    hipLaunchKernelGGL((cpf::k_cp_layered<NQ, LW, ROT, PPT, 0, UD...>), dim3((unsigned)S), dim3(64 << LW), lds, stream, a);
+    cpf::KArgs a = a_in;
+    a.group = layered_group(plan, LW, S, lds);
+    hipLaunchKernelGGL((cpf::k_cp_layered<NQ, LW, ROT, PPT, 0, UD...>), dim3((unsigned)((S + a.group - 1) / a.group)), dim3((64 << LW) * a.group),
+                       lds * a.group, stream, a);
     CPF_HIP(hipGetLastError());
     return 0;
 }
@@ -314,11 +329,11 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
     constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
     const int ppt = (a.P + (64 << lw) - 1) / (64 << lw);
     if (plan->NQ == 4 && lw == 0 && ppt == 3 && plan->layer_ud == std::vector<int>{0, 2, 2, 3, 3, 1}) {      // chain_layer(4) relabelled (fill_plan_shape)
-        *rc = launch_layered_aot<4, 0, XYZ, 3, 0, 2, 2, 3, 3, 1>(a, plan->K, S, stream);
+        *rc = launch_layered_aot<4, 0, XYZ, 3, 0, 2, 2, 3, 3, 1>(plan, a, plan->K, S, stream);
         return true;
     }
     if (plan->NQ == 6 && lw == 2 && ppt == 2 && plan->layer_ud == std::vector<int>{0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0}) {
-        *rc = launch_layered_aot<6, 2, XYZ, 2, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0>(a, plan->K, S, stream);
+        *rc = launch_layered_aot<6, 2, XYZ, 2, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0>(plan, a, plan->K, S, stream);
         return true;
     }
     return false;
@@ -459,7 +474,7 @@ bool try_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t strea
 
 // ---- runtime-specialised kernels (cpf_jit.h).  Which kernels a (plan, S, lw) launch would try, in order of
 // preference: used by the launch path and by cpf_jit_precompile (which builds them without a GPU).
-struct JitCandidate { cpf_jit::Spec spec; size_t lds = 0; std::string tag; };
+struct JitCandidate { cpf_jit::Spec spec; size_t lds = 0; std::string tag; int group = 1, block = 0; };   // block: threads per workgroup of the launch (0: spec.threads)
 
 int ppt_bucket(int ppt) {          // angles per owner thread, rounded up to a few sizes so that adaptive searches over K share kernels
     for (int b : {1, 2, 3, 4, 6, 8, 12}) if (ppt <= b) return b;
@@ -516,8 +531,10 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
     lds *= sizeof(float);
     if (lds > 64 * 1024) { plan->jit_note = "LDS footprint above 64 KiB"; return out; }
     JitCandidate c;
-    c.lds = lds;
-    c.spec = {"cpf_layered.h", cpf_jit::body_expr("layered_body", {plan->NQ, lw, rot_code, ppt, mstore}, plan->layer_ud), threads};
+    c.group = layered_group(plan, lw, S, lds);
+    c.lds = lds * c.group;
+    c.block = threads * c.group;
+    c.spec = {"cpf_layered.h", cpf_jit::body_expr("layered_body", {plan->NQ, lw, rot_code, ppt, mstore}, plan->layer_ud), lw == 0 ? 256 : threads};   // launch bound: up to four one-wave samples per workgroup
     c.tag = std::string("layered/jit(%s) waves=") + (lw ? "4" : "1");
     out.push_back(c);
     return out;
@@ -541,8 +558,10 @@ int precompile_landed(const cpf_jit::Code& code, const std::string& body) {
 
 int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const cpf_jit::Kernel& k, int64_t S, hipStream_t stream) {
     cpf::KArgs args = a;
+    args.group = c.group;
     void* params[] = {&args};
-    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)c.spec.threads, 1, 1, (unsigned)c.lds, stream, params, nullptr);
+    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)((S + c.group - 1) / c.group), 1, 1, (unsigned)(c.block ? c.block : c.spec.threads), 1, 1,
+                                               (unsigned)c.lds, stream, params, nullptr);
     plan->variant = tag_with_backend(c.tag, k.backend);
     return e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
 }
@@ -589,7 +608,7 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
     int lw = 0;
     // measured on MI355X: n=4 S=2048: 1 wave 9.9 ms vs 4 waves 17.0 ms; n=5 S=1000: 1 wave 22.4 ms vs 4 waves 29.6 ms
     switch (plan->NQ) {
-        case 4: lw = (S >= simds) ? 0 : 2; break;
+        case 4: lw = (2 * S > simds) ? 0 : 2; break;       // round 3 (shears, merged Rz pairs, grouped launches): 520-900 samples 26-27 ms on one wave against 35-47 on four
         case 5: lw = (2 * S >= simds) ? 0 : 2; break;
         case 6: lw = 2; break;
         default: lw = 0;
@@ -695,7 +714,7 @@ int32_t cpf_device_count(void) {
 const char* cpf_last_error(void) { return g_err; }
 
 int32_t cpf_set_tuning(const char* name, const char* value) {
-    static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW",
+    static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
                                         "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_RELABEL", "CPF_FORCE_GENERIC",
                                         "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");

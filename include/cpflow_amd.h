@@ -146,7 +146,7 @@ int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
  * one line per kernel in buf, or a negative error code. */
 int32_t cpf_jit_compiles(void);
 /* Kernel-selection switches for tests and A/B measurements (no counterpart in the reference): name is one of "CPF_SPLIT",
- * "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_DENSE", "CPF_DENSE_LW",
+ * "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP", "CPF_DENSE", "CPF_DENSE_LW",
  * "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_RELABEL", "CPF_FORCE_GENERIC", "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"; value
  * NULL restores the default.  Process-wide; plans read the switches when they are created and at every launch.  The
  * release library does not read these names from the environment.  Returns 0, or -1 for an unknown name. */

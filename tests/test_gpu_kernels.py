@@ -568,6 +568,29 @@ def test_every_shipped_block_count(layer, rot, monkeypatch, tune):
     assert _ffi.lib().cpf_jit_compiles() == before
 
 
+@pytest.mark.parametrize('layer,K,rot,S', [([[0, 1], [1, 2], [2, 3]], 9, 'xyz', 301), ([[0, 1], [1, 2], [2, 3], [3, 4]], 7, 'xz', 258)])
+def test_grouped_one_wave_launches_are_bit_identical(layer, K, rot, S, tune):
+    """One-wave layered kernels of 4 and 5 qubits put up to four samples (one per wave) in a workgroup when a launch would
+    otherwise leave it to the dispatcher whether a SIMD gets one wave or two (cpflow_amd.hip layered_group): the same arithmetic
+    per sample, so every output is bit-identical with 1, 2 and 4 samples per workgroup, also when the last workgroup is partly
+    empty (301 = 4 * 75 + 1); the default picks 4 between 257 and 2047 samples."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 51)
+    tune.set('CPF_LW', '0')
+    tune.set('CPF_DENSE', '0')
+    res = {}
+    for g in ('1', '2', '4', None):
+        tune.unset('CPF_GROUP') if g is None else tune.set('CPF_GROUP', g)
+        eng = _engine(layer, K, target, rot, num_gd_iterations=40, r=0.002)
+        out = eng.optimize(eng.initial_angles(2, S), keep_history=True)
+        assert eng.last_variant().startswith('layered/') and eng.last_variant().endswith('waves=1'), eng.last_variant()
+        res[g] = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
+    for g in ('2', '4', None):
+        for k in res['1']:
+            assert np.array_equal(res['1'][k], res[g][k]), (g, k)
+    assert np.isfinite(res['1']['regloss']).all() and (res['1']['regloss'][:, 1] <= res['1']['regloss'][:, 0]).all()
+
+
 def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch, tune):
     """Same inputs through both 3-qubit kernels: identical first losses up to rounding, the same CZ counts on a
     short run, the same end-of-run statistics on config 2's shape; the relative-phase loss (non-linear
