@@ -83,10 +83,10 @@ def precompile_shapes():
     shapes += [(layer, 'xyz', K, 1000, 'cz') for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     # 3 qubits, the block counts an adaptive search over the reference's layers visits (tutorial/results/toff3_chain:
     # 10..20): two-ended kernels specialised on the block count, which a launch picks up when it finds them (nothing
-    # compiles them at run time).  One per regime of samples per CU: one (<= 256 samples), a few with stored states
-    # (how many depends on K), saturated.  A few seconds of hipcc each.
+    # compiles them at run time).  One per regime of samples per CU: one (<= 256 samples), two (both in one workgroup),
+    # a few with stored states (how many depends on K), saturated.  A few seconds of hipcc each.
     shapes += [(layer, rot, K, S, 'cp', {'CPF_JIT_K': '1'}) for layer in (chain3, conn3) for rot in ('xyz', 'xz')
-               for K in range(6, 25) for S in (100, 512, 2048, 8192)]
+               for K in range(6, 25) for S in (100, 400, 700, 2048, 8192)]
     # ... and the 'cz' template runs above (1000 starts: a few samples per CU)
     shapes += [(layer, 'xyz', K, 1000, 'cz', {'CPF_JIT_K': '1'}) for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     return shapes

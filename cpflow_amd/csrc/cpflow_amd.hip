@@ -172,6 +172,13 @@ int launch_variant(const cpf::KArgs& a, int64_t S, hipStream_t stream) {
     return 0;
 }
 
+// More than 64 KiB of dynamic LDS for a kernel loaded from a code object: ROCm 7 takes the hipFunction_t in hipFuncSetAttribute
+// (and launches such a kernel even without it; measured with a 100 KB kernel on the MI355X boxes).  False: keep to 64 KiB.
+bool module_lds_opt_in(hipFunction_t fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 // Ahead-of-time instances of the layered kernel: 3 qubits, the reference's two layer constructors
 // (chain_layer(3), connected_layer(3); topology.py:7-12), 'xyz' / 'xz', optimiser state for <= 128 / 256 angles.
 // Stored phases cost 512 (K + 1) bytes of LDS per sample: use them while that does not cut the number of
@@ -305,9 +312,9 @@ bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipS
 int layered_group(const cpf_plan* plan, int lw, int64_t S, size_t lds_per_sample) {
     int g = 1;
     // not for launches that fill every SIMD twice anyway (config 4, 2048 samples: 45.6 ms single, 45.8 grouped)
-    if (lw == 0 && plan->NQ >= 4 && S > plan->num_cu && S < 8 * (int64_t)plan->num_cu) g = 4 * lds_per_sample <= 64 * 1024 ? 4 : (2 * lds_per_sample <= 64 * 1024 ? 2 : 1);
+    if (lw == 0 && plan->NQ >= 4 && S > plan->num_cu && S < 8 * (int64_t)plan->num_cu) g = 4;
     { const char* e = tuning("CPF_GROUP"); if (e && lw == 0 && plan->NQ >= 4) g = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1); }      // A/B and tests
-    while (g > 1 && (size_t)g * lds_per_sample > 64 * 1024) g >>= 1;
+    while (g > 1 && (int64_t)g * (int64_t)lds_per_sample > plan->lds_per_cu) g >>= 1;        // above 64 KiB per workgroup: opted in at the launch
     return g;
 }
 template <int NQ, int LW, int ROT, int PPT, int... UD>
@@ -316,6 +323,8 @@ int launch_layered_aot(const cpf_plan* plan, const cpf::KArgs& a_in, int K, int6
     if (lds > 64 * 1024) return fail(-20, "LDS footprint above 64 KiB");
     cpf::KArgs a = a_in;
     a.group = layered_group(plan, LW, S, lds);
+    if (lds * a.group > 64 * 1024)
+        CPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_layered<NQ, LW, ROT, PPT, 0, UD...>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds * a.group)));
     hipLaunchKernelGGL((cpf::k_cp_layered<NQ, LW, ROT, PPT, 0, UD...>), dim3((unsigned)((S + a.group - 1) / a.group)), dim3((64 << LW) * a.group),
                        lds * a.group, stream, a);
     CPF_HIP(hipGetLastError());
@@ -438,13 +447,10 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     if (specialised) {
         const int rot = dense_rot_code(plan);
         const bool have_aot = dense_has_aot(nq, lw, rot, plan->layer_ud);
-        // a module kernel cannot opt in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute takes a registered host
-        // symbol): such shapes (K >~ 100 at 6 qubits) take the ahead-of-time table kernel below
-        if (!have_aot && plan->use_jit && lds > 64 * 1024) plan->jit_note = "LDS footprint above 64 KiB";
-        if (!have_aot && plan->use_jit && lds <= 64 * 1024) {
+        if (!have_aot && plan->use_jit) {
             const cpf_jit::Spec spec = dense_jit_spec(nq, lw, rot, plan->layer_ud);
             const cpf_jit::Kernel& k = cpf_jit::get(plan->device, spec);
-            if (k.fn) {
+            if (k.fn && module_lds_opt_in(k.fn, lds)) {
                 cpf::DenseArgs args = da;
                 void* params[] = {&args};
                 e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
@@ -504,15 +510,26 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
         const bool states = states_fit(plan, S, rot_code, slds2);
         int smstore = (states ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
-        // one sample per CU: the K-specialised kernel with the balanced cut (MSTORE bit 17, see launch_split3)
-        bool lone = jit_k && states && (S + plan->num_cu - 1) / plan->num_cu == 1;
-        { const char* e = tuning("CPF_PAIRS"); if (e) lone = lone && e[0] == '1'; }                   // A/B and tests: 0 = the saturated form
-        if (lone) smstore += 2 << 16;
+        // one / two samples per CU: the K-specialised kernel with the balanced cut (MSTORE bit 17), at two per CU with both
+        // samples in one workgroup (bit 16) - the forms of launch_split3, same choice
+        const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
+        int pairs = !jit_k ? 0 : (per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0));
+        { const char* e = tuning("CPF_PAIRS"); if (e && jit_k) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
+        if (pairs == 2 && (S < 2 || cpf::rot_nr(rot_code) < 2 || slds2 > 64 * 1024 ||
+                           ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * slds2) > plan->lds_per_cu)) pairs = per_cu == 1 ? 1 : 0;
+        if (pairs == 1 && !states) pairs = 0;
         JitCandidate c;
-        c.lds = states ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
-        c.spec = {"cpf_split.h", cpf_jit::body_expr("split_body", {rot_code, sppt, smstore}, plan->layer_ud), 128};
-        c.tag = std::string(states ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (jit_k ? " K" : "") + (lone ? " lone" : "");
-        if (c.lds <= 64 * 1024) out.push_back(c);
+        if (pairs == 2) {
+            smstore = 2 + 4 * plan->K + (3 << 16);
+            c.group = 2; c.block = 256; c.lds = 2 * slds2;
+        } else {
+            if (pairs == 1) smstore += 2 << 16;
+            c.lds = states ? slds2 : (size_t)cpf::SplitLds::total(plan->K, 1) * sizeof(float);
+        }
+        c.spec = {"cpf_split.h", cpf_jit::body_expr("split_body", {rot_code, sppt, smstore}, plan->layer_ud), pairs == 2 ? 256 : 128};
+        c.tag = std::string((smstore & 3) == 2 ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (jit_k ? " K" : "") +
+                (pairs == 2 ? " pairs=2" : (pairs == 1 ? " lone" : ""));
+        if (c.lds <= 64 * 1024 || pairs == 2) out.push_back(c);
     }
     if (only_split) return out;
     int mstore = 0;
@@ -559,6 +576,7 @@ int precompile_landed(const cpf_jit::Code& code, const std::string& body) {
 int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const cpf_jit::Kernel& k, int64_t S, hipStream_t stream) {
     cpf::KArgs args = a;
     args.group = c.group;
+    if (!module_lds_opt_in(k.fn, c.lds)) return fail(-20, "%zu B of dynamic LDS refused for a run-time built kernel", c.lds);
     void* params[] = {&args};
     const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)((S + c.group - 1) / c.group), 1, 1, (unsigned)(c.block ? c.block : c.spec.threads), 1, 1,
                                                (unsigned)c.lds, stream, params, nullptr);

@@ -492,13 +492,15 @@ def test_two_ended_kernel_forms_by_samples_per_cu(layer, K, pairs, S, variant, m
     assert (hp[:, -1, 2::3] != init[:, 2::3]).any()
 
 
-@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 14, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 19, 'xyz'), ([[0, 1], [1, 2]], 9, 'xz')])
+@pytest.mark.parametrize('layer,K,rot', [([[0, 1], [1, 2]], 14, 'xyz'), ([[0, 1], [0, 2], [1, 2]], 13, 'xyz'), ([[0, 1], [1, 2]], 9, 'xz')])
 @pytest.mark.parametrize('knobs,S,variant', [({}, 5, 'split/jit(hipcc) waves=2 states K lone'), ({'CPF_PAIRS': '0'}, 6, 'split/jit(hipcc) waves=2 states K'),
+                                             ({'CPF_PAIRS': '2'}, 7, 'split/jit(hipcc) waves=2 states K pairs=2'),
                                              ({'CPF_PSTORE': '0'}, 7, 'split/jit(hipcc) waves=2 K')])
 def test_shipped_block_count_specialised_kernels(layer, K, rot, knobs, S, variant, monkeypatch, tune):
     """3 qubits, block counts other than the BASELINE ones (an adaptive search over chain_layer(3) / connected_layer(3),
     tutorial/results/toff3_chain): the launch picks up the K-specialised two-ended kernels that
-    `python -m cpflow_amd.build --precompile` shipped - one per regime of samples per CU - and compiles nothing; a block
+    `python -m cpflow_amd.build --precompile` shipped - one per regime of samples per CU, the two-samples-per-workgroup form
+    (up to 160 KB of LDS per workgroup, opted in at the launch) among them - and compiles nothing; a block
     count nobody shipped runs on the kernel that reads K from the plan, with compilation still forbidden.  Each form
     against the float64 oracle (history, penalty, frozen mask)."""
     from cpflow_amd import _ffi

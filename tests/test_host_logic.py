@@ -215,7 +215,7 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
 def test_block_count_specialised_kernels_per_regime():
     """3 qubits: the K-specialised two-ended kernel a launch would look up, by samples per CU (cpflow_amd.hip
     jit_candidates with k_mode 1; MSTORE = form + 4 K + the balanced-cut bit 17): one sample per CU -> stored states and the
-    balanced cut, a few per CU -> stored states, saturated -> un-apply.  All three are in the shipped cache for the block
+    balanced cut, two -> that with both samples in one workgroup, a few per CU -> stored states, saturated -> un-apply.  All three are in the shipped cache for the block
     counts of an adaptive search (build.precompile_shapes), so FORBID_COMPILE does not bite."""
     import json
     import subprocess
@@ -229,13 +229,14 @@ def test_block_count_specialised_kernels_per_regime():
         assert r.returncode == 0, r.stderr
         return json.loads(r.stdout.strip().splitlines()[-1])[0]
     assert kernels(14, 100).startswith(f'split/jit(hipcc) waves=2 states K lone [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (2 << 16)}, 0, 1, 1, 2>')
-    assert kernels(14, 512).startswith(f'split/jit(hipcc) waves=2 states K [cached] cpf::split_body<8451, 1, {2 + 4 * 14}, 0, 1, 1, 2>')
+    assert kernels(14, 512).startswith(f'split/jit(hipcc) waves=2 states K pairs=2 [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (3 << 16)}, 0, 1, 1, 2>')
+    assert kernels(14, 700).startswith(f'split/jit(hipcc) waves=2 states K [cached] cpf::split_body<8451, 1, {2 + 4 * 14}, 0, 1, 1, 2>')
     assert kernels(14, 8192).startswith(f'split/jit(hipcc) waves=2 K [cached] cpf::split_body<8451, 1, {1 + 4 * 14}, 0, 1, 1, 2>')
     assert kernels(20, 100).startswith('split/jit(hipcc) waves=2 states K lone [cached]')
     assert kernels(24, 100).startswith('split/jit(hipcc) waves=2 K [cached]')              # stored states above 64 KB of LDS: not built
     from cpflow_amd.build import precompile_shapes
     ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
-    assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 512, 2048, 8192}
+    assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 400, 700, 2048, 8192}
     assert {(s[2], s[3]) for s in ks if s[4] == 'cz'} == {(K, 1000) for K in range(2, 17, 2)}        # the 'cz' template study
 
 
