@@ -204,9 +204,10 @@ bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int ro
 bool kspec_enabled() { const char* e = tuning("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
 // Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
 // them while LDS still admits the workgroups the launch wants on a CU.
-bool states_fit(const cpf_plan* plan, int64_t S, int rot_code, size_t lds_bytes_with_states) {
+// cap: 64 KiB for the kernels built into the library (launched without an LDS opt-in), the CU's LDS for run-time built ones
+bool states_fit(const cpf_plan* plan, int64_t S, int rot_code, size_t lds_bytes_with_states, size_t cap = 64 * 1024) {
     const int num_cu = plan->num_cu;
-    if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > 64 * 1024) return false;
+    if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > cap) return false;
     { const char* e = tuning("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // only while every workgroup of the launch is resident at once (same box, config 2 shape: S = 1024 6.95 vs 7.15 ms
     // with / without states, S = 2048 17.5 vs 15.1, S = 4096 32.1 vs 22.8)
@@ -508,14 +509,14 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = ppt_bucket((P + 127) / 128);
         const size_t slds2 = (size_t)cpf::SplitLds::total(plan->K, 2, 2 * (plan->n_rot - 1)) * sizeof(float);
-        const bool states = states_fit(plan, S, rot_code, slds2);
+        const bool states = states_fit(plan, S, rot_code, slds2, (size_t)plan->lds_per_cu);
         int smstore = (states ? 2 : 1) + (jit_k ? 4 * plan->K : 0);
         // one / two samples per CU: the K-specialised kernel with the balanced cut (MSTORE bit 17), at two per CU with both
         // samples in one workgroup (bit 16) - the forms of launch_split3, same choice
         const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
         int pairs = !jit_k ? 0 : (per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0));
         { const char* e = tuning("CPF_PAIRS"); if (e && jit_k) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
-        if (pairs == 2 && (S < 2 || cpf::rot_nr(rot_code) < 2 || slds2 > 64 * 1024 ||
+        if (pairs == 2 && (S < 2 || cpf::rot_nr(rot_code) < 2 ||
                            ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * slds2) > plan->lds_per_cu)) pairs = per_cu == 1 ? 1 : 0;
         if (pairs == 1 && !states) pairs = 0;
         JitCandidate c;
@@ -529,7 +530,7 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
         c.spec = {"cpf_split.h", cpf_jit::body_expr("split_body", {rot_code, sppt, smstore}, plan->layer_ud), pairs == 2 ? 256 : 128};
         c.tag = std::string((smstore & 3) == 2 ? "split/jit(%s) waves=2 states" : "split/jit(%s) waves=2") + (jit_k ? " K" : "") +
                 (pairs == 2 ? " pairs=2" : (pairs == 1 ? " lone" : ""));
-        if (c.lds <= 64 * 1024 || pairs == 2) out.push_back(c);
+        if ((int64_t)c.lds <= plan->lds_per_cu) out.push_back(c);
     }
     if (only_split) return out;
     int mstore = 0;

@@ -43,6 +43,7 @@ def configs():
     c['n5conn'] = ([[i, j] for i in range(5) for j in range(i + 1, 5)], 57, rand_u(5, 3), [2000])   # ... res_4gt10-v1_81 ('xz' there)
     c['n3k14'] = ([[0, 1], [1, 2]], 14, rand_u(3, 4), [100])                            # the adaptive tutorial's shape (toff3_chain)
     c['n3cz8'] = ([[0, 1], [0, 2], [1, 2]], 8, rand_u(3, 6), [1000])                     # paper/results/local_minimums: Ansatz(3, 'cz', ...)
+    c['n3k24'] = ([[0, 1], [1, 2]], 24, rand_u(3, 7), [100])
     c['n3c18'] = ([[0, 1], [0, 2], [1, 2]], 18, rand_u(3, 5), [100])
     return c
 
