@@ -60,6 +60,9 @@ struct LayeredLds {                                       // float offsets; [0, 
     }
 };
 
+#ifndef CPF_SHARE_PARTNER
+#define CPF_SHARE_PARTNER 1   // A/B: 0 = gradient and un-application of a lane-qubit rotation fetch psi's partners separately
+#endif
 template <class L, int KIND, int Q, bool SH = false>
 __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s);
 template <class L>
@@ -161,6 +164,33 @@ __device__ __forceinline__ float lay_rot_bwd(State<L>& st, float c, float s) {
     constexpr bool LATE = L::row_on_lane(Q) && L::E > 1 && KIND != OP_RZ;
     static_assert(!SH || shear_gate<L, KIND, Q>(), "shear form: a block's x / y rotation on a register qubit");
     float d = 0.f;
+#if CPF_SHARE_PARTNER
+    if constexpr (LATE) {
+        // Lane qubit, several amplitudes per lane: psi's partner amplitudes are fetched ONCE (two DPP moves per amplitude) and
+        // serve both the gradient - read before the gate is un-applied, with the C that belongs to that psi - and psi's
+        // un-application, which then is packed arithmetic: 8 DPP + 12 packed instructions per gate at 4 amplitudes per lane
+        // where separate fetches folded into multiplies cost 16 DPP + 8 (a DPP instruction takes a double issue slot).
+        constexpr int BIT = L::row_bit(Q);
+        f2 acc = {0.f, 0.f};
+        const float ss = KIND == OP_RY ? -st.sg[Q] * s : -s;          // the inverse rotation's sine (y: with the lane's sign)
+#pragma unroll
+        for (int e = 0; e < L::E; e++) {
+            const f2 pp = {xor_lane<BIT>(st.p[e].x), xor_lane<BIT>(st.p[e].y)};
+            if constexpr (KIND == OP_RX) {
+                acc = pk_fma(st.c[e], swp(pp), acc);                    // (Cr X(psi_i), Ci X(psi_r))
+                st.p[e] = pk_fma(f2{ss, -ss}, swp(pp), splat(c) * st.p[e]);
+            } else {
+                acc = pk_fma(st.c[e], pp, acc);                         // (Cr X(psi_r), Ci X(psi_i))
+                st.p[e] = pk_fma(splat(ss), pp, splat(c) * st.p[e]);
+            }
+        }
+        d = KIND == OP_RX ? acc.x - acc.y : st.sg[Q] * (acc.x + acc.y);
+        gate_fence<L>();
+        rot_apply<L, KIND, Q>(st.c, c, -s, st);
+        gate_fence<L>();
+        return d;
+    }
+#endif
     if constexpr (!LATE) { d = rot_grad<L, KIND, Q>(st); gate_fence<L>(); }
     rot_apply<L, KIND, Q, SH>(st.p, SH ? -c : c, -s, st);
     gate_fence<L>();
