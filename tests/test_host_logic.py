@@ -240,6 +240,41 @@ def test_block_count_specialised_kernels_per_regime():
     assert {(s[2], s[3]) for s in ks if s[4] == 'cz'} == {(K, 1000) for K in range(2, 17, 2)}        # the 'cz' template study
 
 
+def test_shear_and_rz_pair_identities():
+    """The algebra behind two forms of the layered kernels (cpflow_amd/csrc/cpf_device.h), restated in NumPy:
+    (i) rot_apply<..., SH>: an x / y rotation as three lifting steps a += u b, b += v a, a += u b with t = tan(theta / 4) =
+    s / (1 + c) taken after the half angle is reduced into [-pi/2, pi/2] (shear_record) equals the reference's gate
+    (gates.py:22-35) up to the global sign the reduction drops, with |t| <= 1; the inverse is the same sequence with (-t, -s);
+    (ii) RzPair: Rz(a) (x) Rz(b) acts on the amplitude with bits (bu, bd) as the phase (cu cd - su sd su' sd') + i (su' su cd +
+    sd' cu sd), sigma' = +1 / -1 for a set / clear bit - the four values the kernel forms from ar, ai, br, bi."""
+    rng = np.random.default_rng(5)
+    X, Y = np.array([[0, 1], [1, 0]], complex), np.array([[0, -1j], [1j, 0]], complex)
+    for theta in list(rng.uniform(-4 * np.pi, 4 * np.pi, 200)) + [np.pi, -np.pi, 3 * np.pi, 2 * np.pi, 0.0, np.float32(np.pi)]:
+        theta = float(theta)                             # float32(pi): cos(theta / 2) = -4.4e-8, the kernel's own case of c < 0 at 'pi'
+        c, s = np.cos(theta / 2), np.sin(theta / 2)
+        sg = -1.0 if c < 0 else 1.0                      # shear_record
+        s2 = s * sg
+        t = s2 / (1 + sg * c)
+        assert abs(t) <= 1 + 1e-12
+        for kind, sigma in (('x', X), ('y', Y)):
+            ref = np.cos(theta / 2) * np.eye(2) - 1j * np.sin(theta / 2) * sigma
+            u, v = (-1j * t, -1j * s2) if kind == 'x' else (-t, s2)
+            up, lo = np.array([[1, u], [0, 1]]), np.array([[1, 0], [v, 1]])
+            m = up @ lo @ up
+            assert np.abs(m - sg * ref).max() < 1e-12
+            upi, loi = np.array([[1, -u], [0, 1]]), np.array([[1, 0], [-v, 1]])
+            assert np.abs(upi @ loi @ upi @ m - np.eye(2)).max() < 1e-12
+    for a, b in rng.uniform(-2 * np.pi, 2 * np.pi, (50, 2)):
+        cu, su, cd, sd = np.cos(a / 2), np.sin(a / 2), np.cos(b / 2), np.sin(b / 2)
+        p, t = cu * cd, cu * sd
+        ar, br, ai, bi = p - su * sd, p + su * sd, su * cd + t, -su * cd + t
+        rz = lambda x: np.diag([np.exp(-1j * x / 2), np.exp(1j * x / 2)])
+        full = np.diag(np.kron(rz(a), rz(b)))            # index 2 bu + bd
+        want = {(1, 1): ar + 1j * ai, (0, 0): ar - 1j * ai, (0, 1): br + 1j * bi, (1, 0): br - 1j * bi}
+        for (bu, bd), z in want.items():
+            assert abs(full[2 * bu + bd] - z) < 1e-12
+
+
 def test_qubit_relabelling_of_the_plan_shape(tmp_path):
     """fill_plan_shape (cpflow_amd.hip): with one wave per sample the 4- / 5-qubit kernels are built around the layer
     with the most-used qubits last (the register qubits); four-wave launches and symmetric layers keep the problem's own
