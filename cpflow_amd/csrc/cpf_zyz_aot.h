@@ -1,0 +1,20 @@
+// cpflow_amd: ahead-of-time instances of the ZYZ-form kernel (cpf_zyz.h), compiled in their own translation unit
+// (cpf_zyz_aot.hip) with the alloca-promotion limits that keep 32 amplitudes per thread in registers (cpf_dense_aot.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace cpf { struct ZyzArgs; struct ZyzlArgs; }
+
+// Launches the layer-specialised instance for (qubits, log2 waves per sample, rotation code, layer) when there is one.
+// Returns 1 = launched (*err receives the launch status), 0 = no such instance.  Instances exist for the rotation string
+// 'xyz' with CP blocks (CPF_DENSE_AOT_ROT) on the BASELINE layers; every other shape is built at run time (cpf_jit.h).
+int cpf_zyz_launch_aot(int nq, int lw, int rot, const std::vector<int>& ud, const cpf::ZyzArgs& za, long long S, size_t lds,
+                       hipStream_t stream, hipError_t* err);
+bool cpf_zyz_has_aot(int nq, int lw, int rot, const std::vector<int>& ud);
+
+// The same for the ZYZ form on the gate-by-gate layout (cpf_zyzl.h; one wave per sample): config 4's chain_layer(4) in the
+// plan's relabelling (0, 1, 2, 3) -> (0, 2, 3, 1).  grid / block: workgroups and threads per workgroup (64 per sample).
+int cpf_zyzl_launch_aot(int nq, int rot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
+                        hipStream_t stream, hipError_t* err);
+bool cpf_zyzl_has_aot(int nq, int rot, const std::vector<int>& ud);

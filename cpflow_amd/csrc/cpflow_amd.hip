@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,9 @@
 #include "cpf_split.h"
 #include "cpf_dense.h"
 #include "cpf_dense_aot.h"
+#include "cpf_zyz.h"
+#include "cpf_zyzl.h"
+#include "cpf_zyz_aot.h"
 #include "cpf_jit.h"
 
 namespace {
@@ -30,15 +34,25 @@ thread_local char g_err[512] = "";
 // cpf_set_tuning (include/cpflow_amd.h) by the tests and the A/B tools.  The release library reads no CPF_* environment
 // variable for them; a build with -DCPF_ENV_TUNING falls back to the environment (tools/).
 std::map<std::string, std::string>& tuning_map() { static std::map<std::string, std::string> m; return m; }
-const char* tuning(const char* name) {
-    auto& m = tuning_map();
-    auto it = m.find(name);
-    if (it != m.end()) return it->second.c_str();
+std::mutex& tuning_mutex() { static std::mutex m; return m; }
+// a switch's value, copied out under the lock (cpf_set_tuning may run on another thread): tests as false when unset
+struct TuneVal {
+    std::string s; bool set = false;
+    explicit operator bool() const { return set; }
+    char operator[](size_t i) const { return i < s.size() ? s[i] : '\0'; }
+};
+TuneVal tuning(const char* name) {
+    TuneVal v;
+    {
+        std::lock_guard<std::mutex> lock(tuning_mutex());
+        auto& m = tuning_map();
+        auto it = m.find(name);
+        if (it != m.end()) { v.s = it->second; v.set = true; return v; }
+    }
 #ifdef CPF_ENV_TUNING
-    return getenv(name);
-#else
-    return nullptr;
+    if (const char* e = getenv(name)) { v.s = e; v.set = true; }
 #endif
+    return v;
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -83,8 +97,13 @@ struct cpf_plan {
     std::vector<int> h_place;        // (up, dn) of every block
     std::vector<int> qperm;          // kernel qubit of problem qubit q
     std::map<int, DevBuf> dense_tab; // per waves-per-sample variant of the dense kernel: its per-block table (cpf_dense.h)
-    DevBuf dense_gmat;               // [samples][K][32] floats: block matrices for the dense kernel's scalar loads (cpf_dense.h)
-    size_t dense_gmat_bytes = 0;
+    // Per-step scratch of the kernels that read per-block tables through the scalar cache (cpf_dense.h: [samples][K][32] floats,
+    // cpf_zyz.h: [samples][K][16]), rebuilt by the kernel every step.  One buffer per stream: launches of one plan on different
+    // streams may overlap, launches on one stream are ordered.
+    struct Scratch { DevBuf buf; size_t bytes = 0; };
+    std::map<hipStream_t, Scratch> scratch;
+    std::mutex scratch_mutex;
+    DevBuf zyz_sides[2];             // static structure of the circuit for the ZYZ-form kernels (cpf_zyz.h ZyzSideInfo), per labelling
     int dense_surf_mask[4] = {0, 0, 0, 0};   // ... and the qubits whose surface gates its sweeps still apply (not folded into a block)
     bool use_jit = true;             // CPF_JIT=0 disables runtime specialisation
     std::string jit_note;            // why the last launch did not use the specialised kernel (diagnostics)
@@ -185,7 +204,7 @@ bool module_lds_opt_in(hipFunction_t fn, size_t bytes) {
 // resident workgroups the launch needs (S / CUs, at most ~5 per SIMD by registers).
 bool phases_fit(const cpf_plan* plan, int64_t S, size_t lds_bytes_with_phases) {
     const int num_cu = plan->num_cu;
-    { const char* e = tuning("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    { const TuneVal e = tuning("CPF_MSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // same-box A/B (ms, store vs rebuild): config 2 S=1024 10.06/10.53, S=4096 24.45/26.15, S=16384 96.1/93.5;
     // config 3 S=1024 12.89/13.75, S=4096 38.5/35.4 -> store only while LDS still admits the workgroups the launch
     // wants per CU (registers cap that at ~20)
@@ -198,17 +217,17 @@ bool phases_fit(const cpf_plan* plan, int64_t S, size_t lds_bytes_with_phases) {
 // (config 2 shape, same box: S = 2048 15.1 vs 17.8 ms, 16384 84.2 vs 93.7 ms; config 3 shape S = 4096 28.8 vs 33.8 ms).
 bool want_split(const cpf_plan* plan, const cpf::KArgs& a, int K, int LL, int rot_code, int64_t S, bool kspec) {
     if (!cpf::layered_merge(3, 0, rot_code) || !cpf::split_supported(K, LL) || a.loss_kind == 2) return false;
-    { const char* e = tuning("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
+    { const TuneVal e = tuning("CPF_SPLIT"); if (e) return e[0] == '1'; }           // A/B and tests
     return kspec || S <= (int64_t)plan->num_cu * 4;
 }
-bool kspec_enabled() { const char* e = tuning("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
+bool kspec_enabled() { const TuneVal e = tuning("CPF_KSPEC"); return !(e && e[0] == '0'); }   // A/B and tests: 0 = K from the plan
 // Stored states (cpf_split.h, MSTORE = 2) cost 512 (NI K + 2) more bytes of LDS per sample (25 KB at config 2): use
 // them while LDS still admits the workgroups the launch wants on a CU.
 // cap: 64 KiB for the kernels built into the library (launched without an LDS opt-in), the CU's LDS for run-time built ones
 bool states_fit(const cpf_plan* plan, int64_t S, int rot_code, size_t lds_bytes_with_states, size_t cap = 64 * 1024) {
     const int num_cu = plan->num_cu;
     if (cpf::rot_nr(rot_code) < 2 || lds_bytes_with_states > cap) return false;
-    { const char* e = tuning("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
+    { const TuneVal e = tuning("CPF_PSTORE"); if (e) return e[0] == '1'; }          // A/B and tests
     // only while every workgroup of the launch is resident at once (same box, config 2 shape: S = 1024 6.95 vs 7.15 ms
     // with / without states, S = 2048 17.5 vs 15.1, S = 4096 32.1 vs 22.8)
     return (int64_t)(plan->lds_per_cu / (int64_t)lds_bytes_with_states) >= (S + num_cu - 1) / num_cu;
@@ -227,7 +246,7 @@ int launch_split3(cpf_plan* plan, const cpf::KArgs& a, int K, int64_t S, hipStre
         // samples), 5.63 -> 4.83 (256).  With four samples per CU neither helps (6.03 -> 6.35 ms at config 2).
         const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
         int pairs = per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0);
-        { const char* e = tuning("CPF_PAIRS"); if (e) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
+        { const TuneVal e = tuning("CPF_PAIRS"); if (e) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
         if (pairs == 2 && (S < 2 || ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * lds2) > plan->lds_per_cu)) pairs = 0;
         if (pairs == 1 && !states_fit(plan, S, ROT, lds2)) pairs = 0;
         if (pairs == 2) {
@@ -289,7 +308,7 @@ bool launch_layered3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S,
     return false;
 }
 bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
+    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
         plan->entangler != CPF_ENTANGLER_CP || plan->K < 1)
         return false;
@@ -314,7 +333,7 @@ int layered_group(const cpf_plan* plan, int lw, int64_t S, size_t lds_per_sample
     int g = 1;
     // not for launches that fill every SIMD twice anyway (config 4, 2048 samples: 45.6 ms single, 45.8 grouped)
     if (lw == 0 && plan->NQ >= 4 && S > plan->num_cu && S < 8 * (int64_t)plan->num_cu) g = 4;
-    { const char* e = tuning("CPF_GROUP"); if (e && lw == 0 && plan->NQ >= 4) g = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1); }      // A/B and tests
+    { const TuneVal e = tuning("CPF_GROUP"); if (e && lw == 0 && plan->NQ >= 4) g = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1); }      // A/B and tests
     while (g > 1 && (int64_t)g * (int64_t)lds_per_sample > plan->lds_per_cu) g >>= 1;        // above 64 KiB per workgroup: opted in at the launch
     return g;
 }
@@ -332,7 +351,7 @@ int launch_layered_aot(const cpf_plan* plan, const cpf::KArgs& a_in, int K, int6
     return 0;
 }
 bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
-    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
+    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP ||
         plan->rot != "xyz")
         return false;
@@ -347,6 +366,23 @@ bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int6
         return true;
     }
     return false;
+}
+
+
+// The scratch buffer of (plan, stream), at least `bytes` large.  Growing it waits for the stream's earlier launches (they
+// read the old buffer) and frees it, which synchronises the device - a one-off per plan and stream for the largest batch.
+int scratch_for(cpf_plan* plan, hipStream_t stream, size_t bytes, float** out) {
+    std::lock_guard<std::mutex> lock(plan->scratch_mutex);
+    cpf_plan::Scratch& sc = plan->scratch[stream];
+    if (bytes > sc.bytes) {
+        CPF_HIP(hipStreamSynchronize(stream));
+        sc.bytes = 0;
+        if (sc.buf.p) { (void)hipFree(sc.buf.p); sc.buf.p = nullptr; }
+        CPF_HIP(sc.buf.alloc(bytes));
+        sc.bytes = bytes;
+    }
+    *out = sc.buf.as<float>();
+    return 0;
 }
 
 // ---- dense-block kernel (cpf_dense.h): 4..6 qubits, any layer / rotation string / entangler.  In order of preference:
@@ -400,11 +436,11 @@ cpf_jit::Spec dense_jit_spec(int nq, int lw, int rot, const std::vector<int>& ud
 }
 bool dense_wanted(const cpf_plan* plan, int mode) {
     if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
-    const char* e = tuning("CPF_DENSE");
+    const TuneVal e = tuning("CPF_DENSE");
     return e ? e[0] != '0' : plan->NQ == 6;
 }
 int dense_lw(const cpf_plan* plan, int64_t S) {
-    const char* w = tuning("CPF_DENSE_LW");
+    const TuneVal w = tuning("CPF_DENSE_LW");
     const int64_t simds = (int64_t)plan->num_cu * 4;
     switch (plan->NQ) {
         case 6: return (w && w[0] == '2') ? 2 : 1;
@@ -413,7 +449,7 @@ int dense_lw(const cpf_plan* plan, int64_t S) {
     }
 }
 bool dense_specialised(const cpf_plan* plan) {
-    const char* sp = tuning("CPF_DENSE_SPECIALISED");               // A/B and tests: 0 = table-dispatched instance only
+    const TuneVal sp = tuning("CPF_DENSE_SPECIALISED");               // A/B and tests: 0 = table-dispatched instance only
     return !(sp && sp[0] == '0') && !plan->layer_ud.empty() && plan->layer_ud.size() <= 32;
 }
 
@@ -433,15 +469,11 @@ int launch_dense(cpf_plan* plan, const cpf::KArgs& a, int nq, int lw, int64_t S,
     const size_t lds = (size_t)cpf::DenseLds(a.P, a.G, plan->K, nq, wps).total * sizeof(float);
     if (lds > (size_t)plan->lds_per_cu) return fail(-20, "dense kernel: %zu B of LDS per sample", lds);
     // global scratch of the scalar-register path: one 128-byte matrix per block and sample, rebuilt every step by the kernel
-    const size_t gbytes = (size_t)S * (size_t)plan->K * 32 * sizeof(float);
-    if (gbytes > plan->dense_gmat_bytes) {
-        CPF_HIP(hipStreamSynchronize(stream));
-        if (plan->dense_gmat.p) { (void)hipFree(plan->dense_gmat.p); plan->dense_gmat.p = nullptr; }
-        CPF_HIP(plan->dense_gmat.alloc(gbytes));
-        plan->dense_gmat_bytes = gbytes;
-    }
-    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot, plan->dense_surf_mask[lw], plan->dense_gmat.as<float>()};
+    // (layer-specialised instances only: the table-dispatched one keeps the matrices in LDS)
     const bool specialised = dense_specialised(plan);
+    float* gmat = nullptr;
+    if (specialised) { if (int rc2 = scratch_for(plan, stream, (size_t)S * (size_t)plan->K * 32 * sizeof(float), &gmat)) return rc2; }
+    const cpf::DenseArgs da{a, tab.as<cpf::DenseBlock>(), plan->K, plan->n_rot, plan->dense_surf_mask[lw], gmat};
     // 1. run-time specialised (shipped cache / compile) unless an ahead-of-time instance of this very layer exists
     hipError_t e = hipSuccess;
     const std::string waves = " waves=" + std::to_string(wps);
@@ -479,6 +511,138 @@ bool try_dense(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t strea
     return true;
 }
 
+
+// ---- ZYZ-form kernel (cpf_zyz.h): the shapes the dense kernel serves whose blocks are CP or CZ, layer-specialised only
+// (ahead of time for the BASELINE layers, at run time otherwise).  Anything else - CX blocks, no compiler and no cached
+// object, more than ZYZ_MAX_BLOCKS blocks - stays on the dense kernel.  CPF_ZYZ=0 switches it off (tests, A/B).
+int zyz_sides(cpf_plan* plan, int which) {          // `which`: the labelling select_labelling() has put into plan->h_place
+    DevBuf& buf = plan->zyz_sides[which];
+    if (buf.p) return 0;
+    const int K = plan->K, n = plan->n;
+    std::vector<cpf::ZyzSideInfo> h((size_t)(2 * K + n));
+    std::vector<int> last((size_t)n, -1);
+    for (auto& e : h) { e.prev = -1; e.qubit = 0; e.pad0 = e.pad1 = 0; for (auto& w : e.later) w = 0; }
+    for (int b = 0; b < K; b++)
+        for (int s = 0; s < 2; s++) {
+            const int w = 2 * b + s, q = plan->h_place[w];
+            h[w].prev = last[q]; h[w].qubit = q;
+            for (int p = last[q]; p >= 0; p = h[p].prev) h[p].later[w >> 6] |= 1ull << (w & 63);       // every earlier side on q sees w as a later one
+            h[2 * K + q].later[w >> 6] |= 1ull << (w & 63);
+            last[q] = w;
+        }
+    for (int q = 0; q < n; q++) { h[2 * K + q].prev = last[q]; h[2 * K + q].qubit = q; }
+    CPF_HIP(buf.alloc(h.size() * sizeof(cpf::ZyzSideInfo)));
+    CPF_HIP(hipMemcpy(buf.p, h.data(), h.size() * sizeof(cpf::ZyzSideInfo), hipMemcpyHostToDevice));
+    return 0;
+}
+cpf_jit::Spec zyz_jit_spec(int nq, int lw, int rot, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyz.h", cpf_jit::body_expr("zyz_body", {nq, lw, rot}, ud), 64 << lw};
+    spec.arg = "cpf::ZyzArgs";
+    spec.min_waves = 2;
+    spec.flags = {CPF_DENSE_MLLVM_FLAGS};
+    return spec;
+}
+bool zyz_wanted(const cpf_plan* plan, int mode) {
+    const TuneVal e = tuning("CPF_ZYZ");
+    if (e && e[0] == '0') return false;
+    return dense_wanted(plan, mode) && dense_specialised(plan) && plan->entangler != CPF_ENTANGLER_CX && plan->K <= cpf::ZYZ_MAX_BLOCKS;
+}
+bool try_zyz(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (!zyz_wanted(plan, a.mode)) return false;
+    const int nq = plan->NQ, lw = dense_lw(plan, S), wps = 1 << lw, threads = 64 << lw, rot = dense_rot_code(plan);
+    const bool have_aot = cpf_zyz_has_aot(nq, lw, rot, plan->layer_ud);
+    const cpf_jit::Kernel* jk = nullptr;
+    if (!have_aot) {
+        if (!plan->use_jit) return false;
+        jk = &cpf_jit::get(plan->device, zyz_jit_spec(nq, lw, rot, plan->layer_ud));
+        if (!jk->fn) { plan->jit_note = jk->error; return false; }      // the dense kernel's own chain reports a forbidden compile
+    }
+    const size_t lds = (size_t)cpf::ZyzLds(a.P, a.G, plan->K, nq, wps).total * sizeof(float);
+    if (lds > (size_t)plan->lds_per_cu) return false;
+    DevBuf& tab = plan->dense_tab[lw];
+    switch (nq * 8 + lw) {
+        case 6 * 8 + 1: *rc = dense_table<cpf::DLay<6, 1>>(plan, tab); break;
+        case 6 * 8 + 2: *rc = dense_table<cpf::DLay<6, 2>>(plan, tab); break;
+        case 5 * 8 + 0: *rc = dense_table<cpf::DLay<5, 0>>(plan, tab); break;
+        case 5 * 8 + 1: *rc = dense_table<cpf::DLay<5, 1>>(plan, tab); break;
+        case 4 * 8 + 0: *rc = dense_table<cpf::DLay<4, 0>>(plan, tab); break;
+        default: return false;
+    }
+    if (*rc) return true;
+    if ((*rc = zyz_sides(plan, 0))) return true;
+    float* scratch = nullptr;
+    if ((*rc = scratch_for(plan, stream, (size_t)S * (size_t)plan->K * cpf::ZYZ_TAB_FLOATS * sizeof(float), &scratch))) return true;
+    const cpf::ZyzArgs za{a, tab.as<cpf::DenseBlock>(), plan->zyz_sides[0].as<cpf::ZyzSideInfo>(), plan->K, plan->n_rot, scratch};
+    const std::string waves = " waves=" + std::to_string(wps);
+    hipError_t e = hipSuccess;
+    if (have_aot) {
+        cpf_zyz_launch_aot(nq, lw, rot, plan->layer_ud, za, S, lds, stream, &e);
+        plan->variant = "zyz/aot" + waves;
+    } else {
+        if (!module_lds_opt_in(jk->fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the ZYZ-form kernel"; return false; }
+        cpf::ZyzArgs args = za;
+        void* params[] = {&args};
+        e = hipModuleLaunchKernel(jk->fn, (unsigned)S, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, stream, params, nullptr);
+        plan->variant = "zyz/jit(" + jk->backend + ")" + waves;
+    }
+    *rc = e == hipSuccess ? 0 : fail((int)e, "ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
+    return true;
+}
+
+// ---- ZYZ form on the gate-by-gate layout (cpf_zyzl.h): one wave per sample, 4 and 5 qubits, CP or CZ blocks,
+// layer-specialised (ahead of time for config 4's relabelled chain, at run time otherwise).  CPF_ZYZL=0|1 switches it.
+cpf_jit::Spec zyzl_jit_spec(int nq, int rot, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyzl.h", cpf_jit::body_expr("zyzl_body", {nq, rot}, ud), 256};      // up to four one-wave samples per workgroup
+    spec.arg = "cpf::ZyzlArgs";
+    spec.min_waves = 1;
+    spec.flags = {CPF_DENSE_MLLVM_FLAGS};
+    return spec;
+}
+bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw != 0 || plan->n != plan->NQ || plan->NQ < 4 || plan->NQ > 5) return false;
+    if (plan->K < 1 || plan->K > cpf::ZYZ_MAX_BLOCKS || plan->n_rot < 1 || plan->n_rot > 8 || plan->entangler == CPF_ENTANGLER_CX) return false;
+    if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
+    const TuneVal e = tuning("CPF_ZYZL");
+    return e ? e[0] != '0' : true;
+}
+bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
+    if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
+    const int nq = plan->NQ, rot = dense_rot_code(plan), which = labelling_for(plan, a_in.mode, lw);
+    const bool have_aot = cpf_zyzl_has_aot(nq, rot, plan->layer_ud);
+    const cpf_jit::Kernel* jk = nullptr;
+    if (!have_aot) {
+        if (!plan->use_jit) return false;
+        jk = &cpf_jit::get(plan->device, zyzl_jit_spec(nq, rot, plan->layer_ud));
+        if (!jk->fn) {
+            plan->jit_note = jk->error;
+            if (jk->error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", jk->error.c_str()); return true; }
+            return false;
+        }
+    }
+    const size_t lds1 = (size_t)cpf::ZyzlLds(a_in.P, a_in.G, plan->K, nq).total * sizeof(float);
+    if (lds1 > (size_t)plan->lds_per_cu) return false;
+    cpf::KArgs a = a_in;
+    a.group = layered_group(plan, lw, S, lds1);
+    const size_t lds = lds1 * a.group;
+    if ((*rc = zyz_sides(plan, which))) return true;
+    const cpf::ZyzlArgs za{a, plan->zyz_sides[which].as<cpf::ZyzSideInfo>(), plan->K, plan->n_rot};
+    const unsigned grid = (unsigned)((S + a.group - 1) / a.group), block = 64u * a.group;
+    hipError_t e = hipSuccess;
+    const std::string tail = std::string(" waves=1") + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
+    if (have_aot) {
+        cpf_zyzl_launch_aot(nq, rot, plan->layer_ud, za, grid, block, lds, stream, &e);
+        plan->variant = "zyzl/aot" + tail;
+    } else {
+        if (!module_lds_opt_in(jk->fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the ZYZ-form kernel"; return false; }
+        cpf::ZyzlArgs args = za;
+        void* params[] = {&args};
+        e = hipModuleLaunchKernel(jk->fn, grid, 1, 1, block, 1, 1, (unsigned)lds, stream, params, nullptr);
+        plan->variant = "zyzl/jit(" + jk->backend + ")" + tail;
+    }
+    *rc = e == hipSuccess ? 0 : fail((int)e, "ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
+    return true;
+}
+
 // ---- runtime-specialised kernels (cpf_jit.h).  Which kernels a (plan, S, lw) launch would try, in order of
 // preference: used by the launch path and by cpf_jit_precompile (which builds them without a GPU).
 struct JitCandidate { cpf_jit::Spec spec; size_t lds = 0; std::string tag; int group = 1, block = 0; };   // block: threads per workgroup of the launch (0: spec.threads)
@@ -504,7 +668,7 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
     const int rot_code = cpf::rot_with_ent(cpf::rot_pack(plan->n_rot, kinds[0], kinds[1], kinds[2]), plan->entangler == CPF_ENTANGLER_CZ ? 1 : (plan->entangler == CPF_ENTANGLER_CX ? 2 : 0));
     cpf::KArgs a{};
     a.loss_kind = loss_kind;
-    const char* jk = tuning("CPF_JIT_K");                                        // opt-in: one build per block count
+    const TuneVal jk = tuning("CPF_JIT_K");                                        // opt-in: one build per block count
     const bool jit_k = k_mode < 0 ? (jk && jk[0] == '1') : k_mode == 1;
     if (plan->NQ == 3 && lw == 0 && want_split(plan, a, plan->K, (int)plan->layer_ud.size() / 2, rot_code, S, jit_k)) {
         const int sppt = ppt_bucket((P + 127) / 128);
@@ -515,7 +679,7 @@ std::vector<JitCandidate> jit_candidates(cpf_plan* plan, int P, int loss_kind, i
         // samples in one workgroup (bit 16) - the forms of launch_split3, same choice
         const int64_t per_cu = (S + plan->num_cu - 1) / plan->num_cu;
         int pairs = !jit_k ? 0 : (per_cu == 2 ? 2 : (per_cu == 1 ? 1 : 0));
-        { const char* e = tuning("CPF_PAIRS"); if (e && jit_k) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
+        { const TuneVal e = tuning("CPF_PAIRS"); if (e && jit_k) pairs = e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0); }      // A/B and tests: 0 = the saturated form
         if (pairs == 2 && (S < 2 || cpf::rot_nr(rot_code) < 2 ||
                            ((S + 1) / 2 + plan->num_cu - 1) / plan->num_cu * (int64_t)(2 * slds2) > plan->lds_per_cu)) pairs = per_cu == 1 ? 1 : 0;
         if (pairs == 1 && !states) pairs = 0;
@@ -591,7 +755,7 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 // block count from the plan.  The tutorial's shape (chain_layer(3), 14 blocks, 100 samples): see DESIGN.md section 4.
 bool try_split3_cached_k(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
     if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || !kspec_enabled()) return false;
-    { const char* e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: the plain runtime build
+    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: the plain runtime build
     const int LL = (int)plan->layer_ud.size() / 2;
     if (plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && ((LL == 2 && plan->K == 12) || (LL == 3 && plan->K == 16)) &&
         (plan->layer_ud == std::vector<int>{0, 1, 1, 2} || plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2}))
@@ -599,6 +763,8 @@ bool try_split3_cached_k(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStre
     for (const JitCandidate& c : jit_candidates(plan, a.P, a.loss_kind, 0, S, 1, true)) {
         const cpf_jit::Kernel& k = cpf_jit::get(plan->device, c.spec, true);
         if (!k.fn) { if (k.error != "not cached") plan->jit_note = k.error; return false; }
+        // an optional kernel: a runtime that refuses its LDS opt-in is a miss, the kernels that read K from the plan follow
+        if (!module_lds_opt_in(k.fn, c.lds)) { plan->jit_note = "dynamic LDS opt-in refused for a shipped K-specialised kernel"; return false; }
         *rc = launch_jit(plan, a, c, k, S, stream);
         return true;
     }
@@ -615,6 +781,7 @@ bool try_layered_jit(cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hip
             if (k.error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", k.error.c_str()); return true; }
             continue;          // next candidate, then the generic kernel
         }
+        if (!module_lds_opt_in(k.fn, c.lds)) { plan->jit_note = "dynamic LDS opt-in refused for a run-time built kernel"; continue; }
         *rc = launch_jit(plan, a, c, k, S, stream);
         return true;
     }
@@ -632,7 +799,7 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
         case 6: lw = 2; break;
         default: lw = 0;
     }
-    { const char* e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
+    { const TuneVal e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
     return lw;
 }
@@ -648,7 +815,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     cpf::KArgs a = a_in;
     a.nsamples = (int)S;
     a.lone = S <= plan->num_cu ? 1 : 0;
-    { const char* e = tuning("CPF_LONE"); if (e) a.lone = e[0] == '1'; }      // A/B and tests
+    { const TuneVal e = tuning("CPF_LONE"); if (e) a.lone = e[0] == '1'; }      // A/B and tests
     {
         const int which = labelling_for(plan, a.mode, lw);
         select_labelling(plan, which);
@@ -658,7 +825,9 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     // reference's own layers); 2. runtime-specialised layered kernel; 3. generic per-gate kernel
     if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
+    if (try_zyz(plan, a, S, stream, &rc)) return rc;
     if (try_dense(plan, a, S, stream, &rc)) return rc;
+    if (try_zyzl(plan, a, lw, S, stream, &rc)) return rc;
     if (try_layered_big_aot(plan, a, lw, S, stream, &rc)) { plan->variant = std::string("layered/aot waves=") + (lw ? "4" : "1"); return rc; }
     if (try_layered_jit(plan, a, lw, S, stream, &rc)) return rc;
     plan->variant = std::string("generic/aot waves=") + (lw ? "4" : "1") + (plan->jit_note.empty() ? "" : " (" + plan->jit_note + ")");
@@ -679,8 +848,8 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     pl->P = 3 * pl->n + pl->nb * pl->K;
     pl->T = pb->num_iterations;
     pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
-    { const char* fg = tuning("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
-    { const char* fj = tuning("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
+    { const TuneVal fg = tuning("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
+    { const TuneVal fj = tuning("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
     // Qubit relabelling (4 and 5 qubits, gate-by-gate kernel, one wave per sample).  That layout keeps the kernel's LAST
     // row qubits in registers (cpf_device.h Lay: a rotation there is 2 packed instructions per amplitude, on a lane qubit 3,
@@ -691,8 +860,8 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     // sample every row qubit sits on lanes and the problem's own labels are kept (the 4-qubit star at 500 samples: 25.2 ms
     // against 28.6 relabelled), hence the choice per launch.
     pl->has_relabel = (pl->NQ == 4 || pl->NQ == 5) && pl->n == pl->NQ;
-    { const char* e = tuning("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
-    { const char* e = tuning("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
+    { const TuneVal e = tuning("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
+    { const TuneVal e = tuning("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
     for (int which = 0; which < 2; which++) {
         cpf_plan::Labelling& lb = pl->lab[which];
         lb.qperm.resize((size_t)pl->n);
@@ -734,11 +903,12 @@ const char* cpf_last_error(void) { return g_err; }
 
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
-                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_RELABEL", "CPF_FORCE_GENERIC",
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
                                         "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {
+            std::lock_guard<std::mutex> lock(tuning_mutex());
             if (value) tuning_map()[name] = value; else tuning_map().erase(name);
             return 0;
         }
@@ -920,7 +1090,7 @@ int32_t cpf_optimize_device(const cpf_plan* plan_c, int64_t S, const float* d_in
     CPF_HIP(hipSetDevice(plan->device));
     cpf::KArgs a = plan->base;
     a.mode = cpf::MODE_OPTIMIZE;
-    { const char* e = tuning("CPF_PRIO"); a.prio = e ? (e[0] == '1') : (S <= (int64_t)plan->num_cu * 8); }   // A/B: CPF_PRIO=0|1
+    { const TuneVal e = tuning("CPF_PRIO"); a.prio = e ? (e[0] == '1') : (S <= (int64_t)plan->num_cu * 8); }   // A/B: CPF_PRIO=0|1
     a.init = d_init; a.frozen = d_frozen;
     a.out_params = d_params; a.out_regloss = d_regloss; a.out_loss = d_loss; a.out_reg = d_reg;
     a.out_cz = d_cz; a.out_pass = d_pass;
@@ -991,8 +1161,18 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     std::string report;
     int built = 0;
     const int loss_kind = pb->loss_kind == CPF_LOSS_RELATIVE_PHASE ? 2 : 0;
-    if (dense_wanted(&pl, cpf::MODE_OPTIMIZE)) {          // the dense-block kernel serves this shape: its layer-specialised instance
+    if (dense_wanted(&pl, cpf::MODE_OPTIMIZE)) {          // the ZYZ-form / dense-block kernels serve this shape: their layer-specialised instances
         const int lw = dense_lw(&pl, num_samples);
+        if (zyz_wanted(&pl, cpf::MODE_OPTIMIZE) && !cpf_zyz_has_aot(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud)) {
+            const cpf_jit::Spec spec = zyz_jit_spec(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud);
+            const cpf_jit::Code code = cpf_jit::build(spec);
+            if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
+            if (int rc = precompile_landed(code, spec.body)) return rc;
+            report = "zyz/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+            built = 1;
+            if (buf && size) snprintf(buf, size, "%s", report.c_str());
+            return built;
+        }
         if (dense_specialised(&pl) && !dense_has_aot(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud)) {
             const cpf_jit::Spec spec = dense_jit_spec(pl.NQ, lw, dense_rot_code(&pl), pl.layer_ud);
             const cpf_jit::Code code = cpf_jit::build(spec);
@@ -1006,6 +1186,14 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     }
     const int lw = choose_lw(&pl, num_samples);
     select_labelling(&pl, labelling_for(&pl, cpf::MODE_OPTIMIZE, lw));
+    if (zyzl_wanted(&pl, cpf::MODE_OPTIMIZE, lw) && !cpf_zyzl_has_aot(pl.NQ, dense_rot_code(&pl), pl.layer_ud)) {
+        const cpf_jit::Spec spec = zyzl_jit_spec(pl.NQ, dense_rot_code(&pl), pl.layer_ud);
+        const cpf_jit::Code code = cpf_jit::build(spec);
+        if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
+        if (int rc = precompile_landed(code, spec.body)) return rc;
+        report += "zyzl/jit(" + code.backend + ") waves=1" + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+        built++;
+    }
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {
         const cpf_jit::Code code = cpf_jit::build(c.spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", c.spec.body.c_str(), code.error.c_str());

@@ -93,7 +93,7 @@ def test_config5_su64_ring_at_size():
     u = wl.target
     assert u.shape == (64, 64) and np.abs(u.conj().T @ u - np.eye(64)).max() < 1e-12 and abs(np.linalg.det(u) - 1) < 1e-9
     variant = _short_run_parity(wl, S=3, T=10, tol=2e-5)
-    assert variant in ('layered/aot waves=4', 'dense/aot waves=2'), variant
+    assert variant in ('layered/aot waves=4', 'dense/aot waves=2', 'zyz/aot waves=2'), variant
     eng = _engine(wl)
     assert eng.num_angles == 438
     S = 1024
@@ -110,7 +110,7 @@ def test_config4_qft_short_run_parity():
     test_full_size_properties[cfg4])."""
     from cpflow_amd import workloads
     variant = _short_run_parity(workloads.CONFIGS['cfg4'], S=5, T=12, tol=1e-5)
-    assert variant.split(' ')[0] in ('layered/aot', 'dense/aot', 'layered/jit(hipcc)', 'dense/jit(hipcc)'), variant     # 5 samples: 4 waves per sample
+    assert variant.split(' ')[0] in ('layered/aot', 'dense/aot', 'zyz/aot', 'layered/jit(hipcc)', 'dense/jit(hipcc)', 'zyz/jit(hipcc)'), variant     # 5 samples: 4 waves per sample
 
 
 def _chi2_two_sample(a, b, bins):
@@ -238,7 +238,7 @@ def test_stored_tutorial_and_paper_shapes_unbiased_against_float32_oracle(name, 
     _unbiased_against_float32_oracle(Trial, int(g['num_samples']), list(range(18, 40, 2)), 0.0, 2e-3, 2e-3, variant, same_flag_min=same_flag_min)
 
 
-@pytest.mark.parametrize('kernel', ['default', 'dense', 'gate-by-gate'])
+@pytest.mark.parametrize('kernel', ['default', 'zyz', 'dense', 'gate-by-gate'])
 def test_config5_unbiased_against_float32_oracle(kernel, tune):
     """Config 5 (6 qubits, ring, 60 blocks, SU(64) target): 128 samples x 2000 iterations on the kernel the plan picks,
     on the dense-block kernel and on the gate-by-gate kernel, each against the float32 oracle.  No run converges
@@ -248,10 +248,14 @@ def test_config5_unbiased_against_float32_oracle(kernel, tune):
     wl = workloads.CONFIGS['cfg5']
     if kernel == 'dense':
         tune.set('CPF_DENSE', '1')
+        tune.set('CPF_ZYZ', '0')
+    elif kernel == 'zyz':
+        tune.set('CPF_DENSE', '1')
+        tune.set('CPF_ZYZ', '1')
     elif kernel == 'gate-by-gate':
         tune.set('CPF_DENSE', '0')
     variant = _unbiased_against_float32_oracle(wl, 128, list(range(60, 121)), 0.5, 4e-3, 4e-3)
-    assert variant.split('/')[0] == {'default': variant.split('/')[0], 'dense': 'dense', 'gate-by-gate': 'layered'}[kernel]
+    assert variant.split('/')[0] == {'default': variant.split('/')[0], 'zyz': 'zyz', 'dense': 'dense', 'gate-by-gate': 'layered'}[kernel]
 
 
 def test_local_minimums_success_ratios():

@@ -686,6 +686,7 @@ def test_dense_block_kernel_matches_oracle(layer, K, rot, ent, lw, how, monkeypa
     target = _rand_unitary(n, 5)
     T, S = 12, 5
     tune.set('CPF_DENSE', '1')
+    tune.set('CPF_ZYZ', '0')                    # the ZYZ-form kernel would take the layer-specialised shapes (its own test below)
     tune.set('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
     if lw is not None:
         tune.set('CPF_DENSE_LW', lw)
@@ -728,6 +729,7 @@ def test_dense_surface_folding_edge_cases(layer, K, how, tune):
     target = _rand_unitary(n, 11)
     T, S = 8, 4
     tune.set('CPF_DENSE', '1')
+    tune.set('CPF_ZYZ', '0')
     tune.set('CPF_DENSE_SPECIALISED', '0' if how == 'table' else '1')
     kw = dict(num_gd_iterations=T, r=0.004)
     orc = Oracle(layer, K, target, 'xyz', **kw)
@@ -744,3 +746,176 @@ def test_dense_surface_folding_edge_cases(layer, K, how, tune):
         assert np.abs(out['history_params'] - ref['history_params'])[:, :2].max() < 3e-5      # the first gradient, surface angles included
         runs[fold] = out
     assert np.abs(runs['1']['history_regloss'] - runs['0']['history_regloss']).max() < 1e-5
+
+
+ZYZ_CASES = [
+    # (layer, K, rot, entangler, CPF_DENSE_LW or None, ahead-of-time instance / run-time build)
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', None, 'aot'),                # 4 qubits: both register bits, both lane bits
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', '0', 'aot'),         # 5 qubits, 1 wave (16 amplitudes per thread)
+    ([[i, (i + 1) % 6] for i in range(6)], 13, 'xyz', 'cp', '1', 'aot'),     # 6 qubits, 2 waves (32 per thread): config 5's kernel, truncated last layer
+    ([[i, (i + 1) % 6] for i in range(6)], 12, 'xyz', 'cp', '2', 'aot'),     # 6 qubits, 4 waves (16 per thread), whole layers only
+    ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cp', '1', 'jit'),            # twisted placements, one letter, two lane qubits
+    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cz', None, 'jit'),          # fixed entangler: no CP angle
+    ([[5, 4], [4, 5], [0, 5], [4, 1]], 6, 'zyxz', 'cp', '2', 'jit'),         # both qubits of a block on lanes; 4 rotation letters (kinds from the records)
+    ([[0, 1], [4, 2]], 3, 'xyz', 'cp', '1', 'jit'),                          # qubits no block touches, fewer blocks than qubits
+    ([[2, 5], [5, 3]], 1, 'xyz', 'cp', '1', 'jit'),                          # a single block
+]
+
+
+@pytest.mark.parametrize('layer,K,rot,ent,lw,how', ZYZ_CASES)
+def test_zyz_form_kernel_matches_oracle(layer, K, rot, ent, lw, how, tune):
+    """The ZYZ-form kernel (cpf_zyz.h: one merged phase per amplitude of the block's pair + two unnormalised real stages, flips
+    pushed onto the initial state, gradients from three generator sums per qubit and block) against the float64 oracle over a
+    short Adam run with history, with the penalty on and with a frozen mask - and with angles that start at the degenerate
+    points of the factorisation (identity rotations, exact flips): every layout variant, CP and CZ blocks, untouched qubits,
+    a single block, a truncated last layer."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 5)
+    T, S = 12, 6
+    tune.set('CPF_DENSE', '1')
+    if lw is not None:
+        tune.set('CPF_DENSE_LW', lw)
+    kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(3, S)
+    nb = 2 * len(rot) + (1 if ent == 'cp' else 0)
+    blk = init[:, 3 * n:].reshape(S, K, nb)
+    blk[4, :, :2 * len(rot)] = 0.0                                            # sample 4: every rotation the identity (t = 0 everywhere)
+    blk[5, :, :2 * len(rot)] = np.float32(np.pi) * np.random.default_rng(1).integers(-1, 3, (K, 2 * len(rot)))     # sample 5: exact flips / identities
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    waves = {None: 1, '0': 1, '1': 2, '2': 4}[lw]
+    assert eng.last_variant() == {'aot': 'zyz/aot', 'jit': 'zyz/jit(hipcc)'}[how] + f' waves={waves}', eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6       # loss at the initial angles
+    assert np.abs(out['history_params'] - ref['history_params'])[:4, :2].max() < 3e-5          # = the first gradient (Adam's first step is lr * sign-like)
+    assert np.abs(out['history_regloss'] - ref['history_loss'])[:4].max() < 2e-5
+    assert np.abs(out['history_params'] - ref['history_params'])[:4].max() < 2e-4
+    # the degenerate starts sit on points where gradients vanish exactly in exact arithmetic: Adam's first step is then decided by
+    # rounding noise, so only the losses they visit are compared with the oracle's own evaluation of the SAME angles
+    for s in (4, 5):
+        for t in (0, T - 1):
+            lg = orc.loss_grad(out['history_params'][s, t][None], np.float64)
+            assert abs(out['history_regloss'][s, t] - lg['regloss'][0]) < 1e-5
+    assert (out['cz'][:4] == ref['cz'][:4]).all() and (out['params'][:, 0] == init).all()
+    assert np.abs(out['reg'] - ref['reg'])[:4].max() < 1e-6
+    hp, best = out['history_params'], out['params'][:, 1]
+    for s in range(S):                                    # the best row is a visited iterate, bit for bit
+        assert any((best[s] == hp[s, t]).all() for t in range(T))
+    frozen = np.zeros((S, orc.P), dtype=np.uint8)
+    frozen[1::2, ::5] = 1
+    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
+    assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
+    tune.set('CPF_DENSE', '0')                  # the gate-by-gate kernels on the same inputs
+    eng0 = _engine(layer, K, target, rot, **kw)
+    out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
+    assert not eng0.last_variant().startswith(('dense', 'zyz'))
+    assert np.abs(outf['regloss'] - out0['regloss'])[:4].max() < 2e-5
+
+
+def test_zyz_form_gradient_at_degenerate_angles(tune):
+    """First Adam step from angles on and next to the degenerate points of the ZYZ factorisation (rotations by 0 and by pi on
+    some blocks, generic elsewhere): the first iterate equals init - lr * g / (|g| + eps) per angle, so comparing it with the
+    float64 oracle's checks every gradient's sign and - through the second iterate - its size."""
+    layer, K, rot = [[i, (i + 1) % 6] for i in range(6)], 12, 'xyz'
+    target = _rand_unitary(6, 9)
+    tune.set('CPF_DENSE_LW', '1')
+    kw = dict(num_gd_iterations=3, r=0.002)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(11, 8)
+    blk = init[:, 18:].reshape(8, K, 7)
+    rng = np.random.default_rng(2)
+    for s in range(8):
+        which = rng.integers(0, K, 5)
+        blk[s, which[:3], 2:4] = np.float32(np.pi) + np.float32(1e-3) * rng.normal(size=(3, 2)).astype(np.float32)   # near-flips: |p| ~ 5e-4
+        blk[s, which[:3], 0:2] = 0.0
+        blk[s, which[3:], 0:4] = np.float32(1e-3) * rng.normal(size=(2, 4)).astype(np.float32)                       # near-identities: t ~ 5e-4
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant() == 'zyz/aot waves=2', eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 1e-5
+    # Adam's first steps are lr * g / (|g| + eps): an angle whose gradient is small moves by the RELATIVE error of that gradient
+    dev = np.abs(out['history_params'] - ref['history_params'])
+    assert dev.max() < 4e-4 and np.mean(dev > 5e-5) < 2e-3, (dev.max(), np.mean(dev > 5e-5))
+
+
+ZYZL_CASES = [
+    # (layer, K, rot, entangler, ahead-of-time instance / run-time build)
+    ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', 'aot'),                      # config 4's layer (relabelled by the plan): lane + register, register + register
+    ([[0, 1], [1, 2], [2, 3]], 24, 'xyz', 'cp', 'aot'),                      # config 4's block count
+    ([[0, 1], [0, 2], [0, 3]], 8, 'xyz', 'cp', 'jit'),                       # 4-qubit star (tutorial/results/toff4_star)
+    ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', 'jit'),                # twisted placements, two letters
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', 'jit'),              # 5 qubits: 16 amplitudes per lane, one lane qubit
+    ([[i, j] for i in range(5) for j in range(i + 1, 5)], 13, 'xz', 'cp', 'jit'),      # 5 qubits all-to-all (paper/results/benchmarks)
+    ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cz', 'jit'),                 # fixed entangler, one letter
+    ([[1, 0], [0, 1], [2, 3]], 7, 'zyxz', 'cp', 'jit'),                      # both qubits of a block on lanes (after relabelling: 2, 3); 4 letters
+    ([[0, 1], [3, 2]], 1, 'xyz', 'cp', 'jit'),                               # a single block, untouched qubits
+]
+
+
+@pytest.mark.parametrize('relabel', ['1', '0'])
+@pytest.mark.parametrize('layer,K,rot,ent,how', ZYZL_CASES)
+def test_zyz_form_on_the_gate_by_gate_layout_matches_oracle(layer, K, rot, ent, how, relabel, tune):
+    """The ZYZ form on the one-wave gate-by-gate layout (cpf_zyzl.h: lane qubits through DPP, register qubits packed) against
+    the float64 oracle over a short Adam run with history, penalty on, frozen mask, degenerate starts; with and without the
+    plan's qubit relabelling (which decides which qubits sit on lanes)."""
+    n = max(max(p) for p in layer) + 1
+    if relabel == '0' and how == 'aot':
+        how = 'jit'                              # the ahead-of-time instance is the relabelled chain
+    target = _rand_unitary(n, 5)
+    T, S = 12, 6
+    tune.set('CPF_LW', '0')
+    tune.set('CPF_ZYZL', '1')
+    tune.set('CPF_RELABEL', relabel)
+    kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(3, S)
+    nb = 2 * len(rot) + (1 if ent == 'cp' else 0)
+    blk = init[:, 3 * n:].reshape(S, K, nb)
+    blk[4, :, :2 * len(rot)] = 0.0
+    blk[5, :, :2 * len(rot)] = np.float32(np.pi) * np.random.default_rng(1).integers(-1, 3, (K, 2 * len(rot)))
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant().startswith({'aot': 'zyzl/aot', 'jit': 'zyzl/jit(hipcc)'}[how] + ' waves=1'), eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6
+    assert np.abs(out['history_params'] - ref['history_params'])[:4, :2].max() < 3e-5
+    assert np.abs(out['history_regloss'] - ref['history_loss'])[:4].max() < 2e-5
+    assert np.abs(out['history_params'] - ref['history_params'])[:4].max() < 2e-4
+    for s in (4, 5):
+        for t in (0, T - 1):
+            lg = orc.loss_grad(out['history_params'][s, t][None], np.float64)
+            assert abs(out['history_regloss'][s, t] - lg['regloss'][0]) < 1e-5
+    assert (out['cz'][:4] == ref['cz'][:4]).all() and (out['params'][:, 0] == init).all()
+    assert np.abs(out['reg'] - ref['reg'])[:4].max() < 1e-6
+    hp, best = out['history_params'], out['params'][:, 1]
+    for s in range(S):
+        assert any((best[s] == hp[s, t]).all() for t in range(T))
+    frozen = np.zeros((S, orc.P), dtype=np.uint8)
+    frozen[1::2, ::5] = 1
+    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
+    assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
+    tune.set('CPF_ZYZL', '0')                   # the gate-by-gate kernel on the same inputs
+    eng0 = _engine(layer, K, target, rot, **kw)
+    out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
+    assert eng0.last_variant().startswith(('layered', 'generic')), eng0.last_variant()      # four rotation letters: the generic kernel
+    assert np.abs(outf['regloss'] - out0['regloss'])[:4].max() < 2e-5
+
+
+def test_zyzl_grouped_launches_are_bit_identical(tune):
+    """Several one-wave samples per workgroup (KArgs::group) are independent: 1, 2 and 4 samples per workgroup give the same bits."""
+    layer, K = [[0, 1], [1, 2], [2, 3]], 9
+    target = _rand_unitary(4, 3)
+    tune.set('CPF_LW', '0')
+    tune.set('CPF_ZYZL', '1')
+    outs = []
+    for g in ('1', '2', '4'):
+        tune.set('CPF_GROUP', g)
+        eng = _engine(layer, K, target, 'xyz', num_gd_iterations=15, r=0.002)
+        init = eng.initial_angles(4, 37)
+        outs.append({k: v.cpu().numpy() for k, v in eng.optimize(init).items()})
+        assert eng.last_variant().startswith('zyzl/aot waves=1'), eng.last_variant()
+    for o in outs[1:]:
+        for k in ('params', 'regloss', 'loss', 'reg', 'cz'):
+            assert (o[k] == outs[0][k]).all(), k
