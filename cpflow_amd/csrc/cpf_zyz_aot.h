@@ -15,6 +15,7 @@ bool cpf_zyz_has_aot(int nq, int lw, int rot, const std::vector<int>& ud);
 
 // The same for the ZYZ form on the gate-by-gate layout (cpf_zyzl.h; one wave per sample): config 4's chain_layer(4) in the
 // plan's relabelling (0, 1, 2, 3) -> (0, 2, 3, 1).  grid / block: workgroups and threads per workgroup (64 per sample).
-int cpf_zyzl_launch_aot(int nq, int rot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
+// nslot: items (sides + qubits) per lane, (2 K + n + 63) / 64; the instance holds one (K <= 30 at 4 qubits).
+int cpf_zyzl_launch_aot(int nq, int rot, int nslot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
                         hipStream_t stream, hipError_t* err);
-bool cpf_zyzl_has_aot(int nq, int rot, const std::vector<int>& ud);
+bool cpf_zyzl_has_aot(int nq, int rot, int nslot, const std::vector<int>& ud);

@@ -36,24 +36,24 @@ int cpf_zyz_launch_aot(int nq, int lw, int rot, const std::vector<int>& ud, cons
 }
 
 namespace {
-template <int NQ, int ROT, int... UD>
+template <int NQ, int ROT, int NSLOT, int... UD>
 hipError_t run_l(const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_zyzl<NQ, ROT, UD...>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_zyzl<NQ, ROT, NSLOT, UD...>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((cpf::k_cp_zyzl<NQ, ROT, UD...>), dim3(grid), dim3(block), lds, stream, za);
+    hipLaunchKernelGGL((cpf::k_cp_zyzl<NQ, ROT, NSLOT, UD...>), dim3(grid), dim3(block), lds, stream, za);
     return hipGetLastError();
 }
 const std::vector<int> CHAIN4_RELABELLED = {0, 2, 2, 3, 3, 1};
 }  // namespace
 
-bool cpf_zyzl_has_aot(int nq, int rot, const std::vector<int>& ud) { return rot == CPF_DENSE_AOT_ROT && nq == 4 && ud == CHAIN4_RELABELLED; }
+bool cpf_zyzl_has_aot(int nq, int rot, int nslot, const std::vector<int>& ud) { return rot == CPF_DENSE_AOT_ROT && nq == 4 && nslot == 1 && ud == CHAIN4_RELABELLED; }
 
-int cpf_zyzl_launch_aot(int nq, int rot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
+int cpf_zyzl_launch_aot(int nq, int rot, int nslot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
                         hipStream_t stream, hipError_t* err) {
-    if (!cpf_zyzl_has_aot(nq, rot, ud)) return 0;
-    *err = run_l<4, CPF_DENSE_AOT_ROT, 0, 2, 2, 3, 3, 1>(za, grid, block, lds, stream);
+    if (!cpf_zyzl_has_aot(nq, rot, nslot, ud)) return 0;
+    *err = run_l<4, CPF_DENSE_AOT_ROT, 1, 0, 2, 2, 3, 3, 1>(za, grid, block, lds, stream);
     return 1;
 }

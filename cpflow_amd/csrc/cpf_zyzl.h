@@ -10,36 +10,33 @@
 // where the gate-by-gate kernel (cpf_layered.h) applies a CP, two x, two y and two z rotations per block.  Backward: the same
 // in reverse on psi and on the cotangent, three generator sums per qubit right after the stages (a lane qubit's partner
 // amplitudes are fetched once and serve its sums and psi's un-application), one sum over the |11> amplitudes before conj(d).
-// Build and chain phases are those of cpf_zyz.h (one thread per side / block / qubit around the sweeps), except that the
-// per-block table stays in LDS.  Up to four samples per workgroup, one per wave (KArgs::group, cpf_layered.h).
+// Build and chain phases follow cpf_zyz.h, but every item (a side of a block, a qubit's surface gate) has an OWNER lane that keeps
+// its angles, Adam state, (cos, sin) and factors in registers from step to step (zyzl_body).  Up to four samples per workgroup, one
+// per wave (KArgs::group, cpf_layered.h).
 #pragma once
 #include "cpf_zyz.h"
 
 namespace cpf {
 
-constexpr int ZYZL_TAB_FLOATS = 12;                  // per block: d_k (re, im), k = 2 a_up + a_dn; t_dn, t_up; two spare
+// per block: k = 2 a_up + a_dn -> (re, im, -im, im) of d_k (the second pair lets d * x be two compiler-scheduled packed instructions:
+// (re, re) is a free half-select of the first pair, (-im, im) would cost an instruction of its own); then t_dn, t_up; two spare
+constexpr int ZYZL_TAB_FLOATS = 20;
 
 struct ZyzlArgs { KArgs k; const ZyzSideInfo* sides; int K, n_rot; };
 
-struct ZyzlLds {                                     // float offsets, per sample
-    int rec, side, binfo, btab, surfm, lfin, msf, fw, th, mm, vv, psl, gw, sums, gsurf, red, total;
+struct ZyzlLds {                                     // float offsets, per sample; [0, 28) = penalty table
+    int side, stat, btab, surfm, lfin, fw, sums, gsurf, total;
     __host__ __device__ static constexpr int up4(int x) { return (x + 3) & ~3; }
-    __host__ __device__ ZyzlLds(int P, int G, int K, int nq) {
-        rec = PEN_FLOATS;
-        side = rec + 4 * G;
-        binfo = side + 16 * K;
-        btab = up4(binfo + 2 * K);
-        surfm = btab + ZYZL_TAB_FLOATS * K;
-        lfin = surfm + 8 * nq;
-        msf = lfin + 4 * nq;
-        fw = up4(msf + nq);
-        th = fw + 8;
-        mm = th + P; vv = mm + P; psl = vv + P;
-        gw = psl + P;
-        sums = up4(gw + G);                    // [K][32]: generator sums, reduce8_rows slabs
+    __host__ __device__ ZyzlLds(int K, int nq) {
+        side = PEN_FLOATS;                     // 2 K x {t, sc, l0, l1, f, -}: the side records
+        stat = side + 16 * K;                  // (2 K + nq) x {prev, qubit, -, -, later masks}: static structure (cpf_zyz.h ZyzSideInfo)
+        btab = stat + 12 * (2 * K + nq);       // K per-block tables
+        surfm = btab + ZYZL_TAB_FLOATS * K;    // nq x 2x2 complex
+        lfin = surfm + 8 * nq;                 // nq x (l0, l1)
+        fw = up4(lfin + 4 * nq);               // 4 x 64 flip bits
+        sums = fw + 8;                         // [K][32]: generator sums, reduce8_rows slabs
         gsurf = sums + K * 32;
-        red = gsurf + ((3 * nq + 7) / 8) * 32;
-        total = up4(red + 8);
+        total = up4(gsurf + ((3 * nq + 7) / 8) * 32);
     }
 };
 
@@ -68,7 +65,7 @@ template <class L, int UP, int DN>
 struct ZlTab {
     static constexpr bool UL = L::row_on_lane(UP), DL = L::row_on_lane(DN);
     static constexpr int NU = UL ? 1 : 2, ND = DL ? 1 : 2, NPH = NU * ND;
-    f2 ph[NPH];
+    f2 ph[NPH], pn[NPH];                  // d_k and (-im, im) of it
     float tu, td;
     __host__ __device__ static constexpr int idx(int e) {           // phase / z-accumulator index of amplitude e
         return (UL ? 0 : ((e >> L::row_bit(UP)) & 1)) * ND + (DL ? 0 : ((e >> L::row_bit(DN)) & 1));
@@ -77,12 +74,17 @@ struct ZlTab {
         return (UL || ((e >> L::row_bit(UP)) & 1)) && (DL || ((e >> L::row_bit(DN)) & 1));
     }
 };
+// The LDS reads of a block's table are issued one block ahead (a block of 4 amplitudes per lane is ~100 instructions: an exposed
+// LDS round trip per block would be a fifth of it): ZlRaw holds what was read, zl_use turns it into the block's ZlTab.
+struct ZlRaw { f2 ph[4], pn[4]; float2 tt; };
+// d * x / conj(d) * x from the table's two pairs: two packed instructions the compiler is free to interleave with its neighbours'
+// (dependent packed instructions issue at half rate: tools/micro/issue_rate.hip)
+__device__ __forceinline__ f2 zl_mul(f2 d, f2 n, f2 x) { return pk_fma(n, swp(x), splat(d.x) * x); }
+__device__ __forceinline__ f2 zl_mul_conj(f2 d, f2 n, f2 x) { return pk_fma(-n, swp(x), splat(d.x) * x); }
 template <class L, int UP, int DN>
-__device__ __forceinline__ void zl_load(ZlTab<L, UP, DN>& t, const float* bt, const ZlLane<L>& ln) {
+__device__ __forceinline__ void zl_load_raw(ZlRaw& r, const float* bt, const ZlLane<L>& ln) {
     using T = ZlTab<L, UP, DN>;
-    const float2 tt = *reinterpret_cast<const float2*>(bt + 8);        // (t_dn, t_up)
-    if constexpr (T::UL) t.tu = ln.sg[UP] * tt.y; else t.tu = tt.y;
-    if constexpr (T::DL) t.td = ln.sg[DN] * tt.x; else t.td = tt.x;
+    r.tt = *reinterpret_cast<const float2*>(bt + 16);                  // (t_dn, t_up)
 #pragma unroll
     for (int iu = 0; iu < T::NU; iu++)
 #pragma unroll
@@ -90,9 +92,18 @@ __device__ __forceinline__ void zl_load(ZlTab<L, UP, DN>& t, const float* bt, co
             int au = iu, ad = id;
             if constexpr (T::UL) au = ln.lb[UP] ? 1 : 0;
             if constexpr (T::DL) ad = ln.lb[DN] ? 1 : 0;
-            const float2 v = *reinterpret_cast<const float2*>(bt + 2 * (2 * au + ad));
-            t.ph[iu * T::ND + id] = f2{v.x, v.y};
+            const float4 v = *reinterpret_cast<const float4*>(bt + 4 * (2 * au + ad));
+            r.ph[iu * T::ND + id] = f2{v.x, v.y};
+            r.pn[iu * T::ND + id] = f2{v.z, v.w};
         }
+}
+template <class L, int UP, int DN>
+__device__ __forceinline__ void zl_use(ZlTab<L, UP, DN>& t, const ZlRaw& r, const ZlLane<L>& ln) {
+    using T = ZlTab<L, UP, DN>;
+    if constexpr (T::UL) t.tu = ln.sg[UP] * r.tt.y; else t.tu = r.tt.y;
+    if constexpr (T::DL) t.td = ln.sg[DN] * r.tt.x; else t.td = r.tt.x;
+#pragma unroll
+    for (int k = 0; k < T::NPH; k++) { t.ph[k] = r.ph[k]; t.pn[k] = r.pn[k]; }
 }
 // one unnormalised stage on qubit Q: (a, b) <- (a - t b, b + t a); t arrives signed for a lane qubit
 template <class L, int Q>
@@ -121,7 +132,7 @@ template <class L, int UP, int DN>
 __device__ __forceinline__ void zl_fwd(f2 (&x)[L::E], const ZlTab<L, UP, DN>& t) {
     using T = ZlTab<L, UP, DN>;
 #pragma unroll
-    for (int e = 0; e < L::E; e++) x[e] = zl_cmul(t.ph[T::idx(e)], x[e]);
+    for (int e = 0; e < L::E; e++) x[e] = zl_mul(t.ph[T::idx(e)], t.pn[T::idx(e)], x[e]);
     zl_stage<L, UP>(x, t.tu);
     zl_stage<L, DN>(x, t.td);
 }
@@ -208,7 +219,7 @@ __device__ __forceinline__ void zl_bwd(f2 (&p)[L::E], f2 (&c)[L::E], const ZlTab
         d8[6] = s11; d8[7] = 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) { p[e] = zl_cmul_conj(t.ph[T::idx(e)], p[e]); c[e] = zl_cmul_conj(t.ph[T::idx(e)], c[e]); }
+    for (int e = 0; e < E; e++) { p[e] = zl_mul_conj(t.ph[T::idx(e)], t.pn[T::idx(e)], p[e]); c[e] = zl_mul_conj(t.ph[T::idx(e)], t.pn[T::idx(e)], c[e]); }
 }
 
 // x[e] = base * prod over the register qubits of f_q[bit of e] (register bit rb holds qubit NLR + rb)
@@ -223,37 +234,37 @@ __device__ __forceinline__ void zl_product(f2 (&x)[L::E], f2 base, const F& fac)
     }, typename make_iseq<L::NRR>::type{});
 }
 
-template <int NQ, int ROT, int... UD>
+// Items: one per side (i = 2 b + side < 2 K), then one per qubit (i = 2 K + q).  Item i belongs to lane i mod 64, slot i / 64 (NSLOT
+// slots per lane, a template argument), and that lane OWNS the item's angles - a side's rotation angles (and, for side 0, the
+// block's CP angle), a qubit's three surface angles: Adam state, (cos, sin), the side's factors and the gradients the chain phase
+// produces all stay in the owner's registers; only what other lanes need crosses LDS (the side records, the per-block tables, the
+// surface matrices, the reduced sums).
+template <int NQ, int ROT, int NSLOT, int... UD>
 __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     using L = Lay<NQ, 0>;
     using PL = PairList<UD...>;
     constexpr int LL = sizeof...(UD) / 2;
-    static_assert(LL > 0, "the ZYZ-form kernel is layer-specialised");
-    constexpr int E = L::E, THREADS = 64, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
+    static_assert(LL > 0 && ROT != 0, "the ZYZ-form kernel is specialised on the layer and the rotation string");
+    constexpr int E = L::E, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
+    constexpr int NR = ROT & 15, ENT = (ROT >> 16) & 3, NBP = 2 * NR + (ENT == 0 ? 1 : 0);
+    static_assert(NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     const KArgs& a = za.k;
     extern __shared__ __attribute__((aligned(16))) float smem_wg[];
-    const int P = a.P, G = a.G, K = za.K, NR = za.n_rot;
-    const ZyzlLds lds(P, G, K, NQ);
-    // one wave per sample; a workgroup may hold several samples, one per wave, each with its own copy of the LDS map
+    const int P = a.P, K = za.K;
+    const ZyzlLds lds(K, NQ);
     const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int tid = (int)threadIdx.x & 63, lane = tid;
     const int64_t s_idx = (int64_t)blockIdx.x * (a.group > 1 ? a.group : 1) + sub;
     if (s_idx >= a.nsamples) return;
     float* smem = smem_wg + sub * lds.total;
-    float4* rec = reinterpret_cast<float4*>(smem + lds.rec);
-    float* th = smem + lds.th;
-    float* mm = smem + lds.mm;
-    float* vv = smem + lds.vv;
-    float* psl = smem + lds.psl;
-    float* gw = smem + lds.gw;
     float4* sidev = reinterpret_cast<float4*>(smem + lds.side);
     unsigned long long* fw = reinterpret_cast<unsigned long long*>(smem + lds.fw);
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
+    float* out_best = a.out_params + (s_idx * 2 + 1) * P;
     const int col = L::col_index(lane, 0);
     const int dst_lane = reduce8_dst_lane(lane);
-    const int per_block = 1 + 2 * NR;
-    const int nw = (2 * K + 63) >> 6;
+    const int nw = (2 * K + 63) >> 6, NI = 2 * K + NQ;
     ZlLane<L> ln;
 #pragma unroll
     for (int i = 0; i < L::NLR; i++) { ln.lb[i] = (lane >> L::row_lane_bit(i)) & 1; ln.sg[i] = ln.lb[i] ? 1.f : -1.f; }
@@ -263,41 +274,66 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     auto target_at = [&](int e) __attribute__((always_inline)) {
         return *reinterpret_cast<const float2*>(tbase + (toff_i + (uint32_t)((L::row_index(0, e)) * L::D * 8)));
     };
-
     penalty_table_init(smem, a, tid);
-    for (int g = tid; g < G; g += THREADS) {
-        const int4 op = a.prog[g];
-        rec[g] = make_float4(op.x == OP_CZ ? -1.f : 1.f, 0.f, __int_as_float(op.x | (op.y << 4) | (op.z << 8)), 0.f);
-    }
-    lds_sync<1>();
-    auto publish = [&](int j, float t) {
-        float sn, cn;
-        const bool cp = a.pkind[j];
-        fast_sincos(cp ? t : 0.5f * t, sn, cn);
-        *reinterpret_cast<float2*>(&rec[a.pgate[j]]) = make_float2(cn, sn);
-    };
-    for (int j = tid; j < P; j += THREADS) {
-        const float t0 = init[j];
-        th[j] = t0; mm[j] = 0.f; vv[j] = 0.f;
-        a.out_params[(s_idx * 2 + 0) * P + j] = t0;
-        a.out_params[(s_idx * 2 + 1) * P + j] = t0;
-        publish(j, t0);
-    }
-    lds_sync<1>();
 
-    auto block_rec = [&](int g0) {
-        return [rec, g0](int i, float& c, float& s, int& kind) {
-            const float4 r = rec[g0 + i];
-            c = r.x; s = r.y; kind = __builtin_amdgcn_readfirstlane(__float_as_int(r.z) & 15);
-        };
-    };
+    // ---- the items of this lane
+    struct Item {
+        float th[4], mm[4], vv[4], g[4], cs[4][2];     // angle k: rotation letter k (side) / surface angle k (qubit); k = 3: the CP angle (side 0)
+        int pj[4];                                     // parameter index, -1 = none
+        bool frz[4];
+        int kind;                                      // 0 = side, 1 = qubit, 2 = none
+        int prev;                                      // side: previous side on the qubit; qubit: last side on it
+        zyz::Side sd;
+        int cacb; float d0, psl, pval;                 // side 0: where the CP phase sits, the block's scale, r * penalty slope, penalty
+        int m;                                         // qubit: all flips on it
+    } itm[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        Item& t = itm[s];
+        const int i = tid + 64 * s;
+        t.kind = i < 2 * K ? 0 : (i < NI ? 1 : 2);
+        t.prev = -1; t.cacb = 0; t.d0 = 1.f; t.psl = 0.f; t.pval = 0.f; t.m = 0;
+        t.sd = zyz::Side{};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { t.pj[k] = -1; t.th[k] = 0.f; t.mm[k] = 0.f; t.vv[k] = 0.f; t.g[k] = 0.f; t.cs[k][0] = 1.f; t.cs[k][1] = 0.f; t.frz[k] = false; }
+        if (t.kind == 0) {
+            const int b = i >> 1, side = i & 1;
+#pragma unroll
+            for (int k = 0; k < NR; k++) t.pj[k] = NS + NBP * b + 2 * k + side;
+            if (ENT == 0 && side == 0) t.pj[3] = NS + NBP * b + 2 * NR;
+            t.prev = za.sides[i].prev;
+        } else if (t.kind == 1) {
+            const int q = i - 2 * K;
+            for (int p = 0; p < NQ; p++)               // the surface gates of kernel qubit q carry the angles of the problem qubit relabelled to q
+                if (a.pgate[3 * p] == 3 * q) { t.pj[0] = 3 * p; t.pj[1] = 3 * p + 1; t.pj[2] = 3 * p + 2; }
+            t.prev = za.sides[i].prev;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (t.pj[k] >= 0) {
+                t.th[k] = init[t.pj[k]];
+                t.frz[k] = frozen && frozen[t.pj[k]];
+                a.out_params[(s_idx * 2) * P + t.pj[k]] = t.th[k];
+                out_best[t.pj[k]] = t.th[k];
+            }
+        }
+        // static structure other lanes need: {prev, -, later masks} per item
+        if (t.kind != 2) {
+            const ZyzSideInfo si = za.sides[i];
+            int* st = reinterpret_cast<int*>(smem + lds.stat + 12 * i);
+            st[0] = si.prev; st[1] = si.qubit;
+            for (int k = 0; k < 4; k++) { st[4 + 2 * k] = (int)(si.later[k] & 0xffffffffull); st[5 + 2 * k] = (int)(si.later[k] >> 32); }
+        }
+    }
+    lds_sync<1>();
     auto load_side = [&](int w) {
         const float4 s0 = sidev[2 * w], s1 = sidev[2 * w + 1];
         zyz::Side sd;
-        sd.t = s0.x; sd.sc = s0.y; sd.l0 = zyz::c2(s0.z, s0.w); sd.l1 = zyz::c2(s1.x, s1.y); sd.f = __float_as_int(s1.z); sd.m = __float_as_int(s1.w);
+        sd.t = s0.x; sd.sc = s0.y; sd.l0 = zyz::c2(s0.z, s0.w); sd.l1 = zyz::c2(s1.x, s1.y); sd.f = __float_as_int(s1.z); sd.m = 0;
         return sd;
     };
-    auto parity = [&](const unsigned long long* mask) {
+    auto parity_of = [&](int i) {                      // flips of the sides item i's mask names
+        const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(smem + lds.stat + 12 * i + 4);
         int n = 0;
         for (int k = 0; k < nw; k++) n += __popcll(fw[k] & mask[k]);
         return n & 1;
@@ -311,55 +347,84 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
-        const float2 bc = const_load_f2(a.bias, a.T > 0 ? it : 0);
+        const float2 bc = const_load_f2(a.bias, a.T > 0 ? (it > 0 ? it - 1 : 0) : 0);          // Adam closes the PREVIOUS step here
         asm volatile("" : "+v"(toff_i), "+v"(lane_i), "+v"(col_i));
-        // ================= build A: one thread per side (cpf_zyz.h)
-        for (int base = 0; base < 2 * K; base += THREADS) {
-            const int w = base + tid;
+        // ================= owner + build A: Adam on the gradients of the previous step, (cos, sin), the side's factors
+        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) {
+            Item& t = itm[s];
             bool flip = false;
-            if (w < 2 * K) {
-                const zyz::Side sd = zyz::side_build<ROT>(block_rec(NS + per_block * (w >> 1)), NR, w & 1);
-                sidev[2 * w] = make_float4(sd.t, sd.sc, sd.l0.re, sd.l0.im);
-                sidev[2 * w + 1] = make_float4(sd.l1.re, sd.l1.im, __int_as_float(sd.f), 0.f);
-                flip = sd.f != 0;
+            if (t.kind != 2) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (t.pj[k] < 0) continue;
+                    if (it > 0 && !t.frz[k]) {
+                        float g = t.g[k];
+                        if (k == 3 && a.use_reg) g += t.psl;
+                        const float m = fmaf(a.b1, t.mm[k], a.omb1 * g);
+                        const float v = fmaf(a.b2, t.vv[k], a.omb2 * (g * g));
+                        t.mm[k] = m; t.vv[k] = v;
+                        t.th[k] = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), t.th[k]);
+                    }
+                    fast_sincos(k == 3 ? t.th[k] : 0.5f * t.th[k], t.cs[k][1], t.cs[k][0]);
+                }
+                if (t.kind == 0) {
+                    if (ENT == 0 && t.pj[3] >= 0 && a.use_reg) {
+                        float sl;
+                        t.pval = penalty_lds(smem, a.pen_kind, t.th[3], sl);
+                        t.psl = a.r * sl;
+                    }
+                    const int side = (tid + 64 * s) & 1;
+                    auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
+                        const int k = (idx - 1) >> 1;
+                        c = t.cs[k][0]; sn = t.cs[k][1]; kind = 0;
+                    };
+                    const int m_keep = t.sd.m;
+                    t.sd = zyz::side_build<ROT>(rrec, NR, side);
+                    t.sd.m = m_keep;
+                    const int w = tid + 64 * s;
+                    sidev[2 * w] = make_float4(t.sd.t, t.sd.sc, t.sd.l0.re, t.sd.l0.im);
+                    sidev[2 * w + 1] = make_float4(t.sd.l1.re, t.sd.l1.im, __int_as_float(t.sd.f), 0.f);
+                    flip = t.sd.f != 0;
+                }
             }
             const unsigned long long bits = __builtin_amdgcn_ballot_w64(flip);
-            if (lane == 0) fw[base >> 6] = bits;
+            if (lane == 0) fw[s] = bits;
         }
         lds_sync<1>();
-        // ================= build B: one thread per block (its table), one per qubit (surface matrix, final left factor)
-        for (int w = tid; w < K + NQ; w += THREADS) {
-            if (w < K) {
-                const int b = w, g0 = NS + per_block * b;
-                const ZyzSideInfo* iu = za.sides + 2 * b;
-                zyz::Side su = load_side(2 * b), sd = load_side(2 * b + 1), pu = su, pd = sd;
-                su.m = parity(iu[0].later); sd.m = parity(iu[1].later);
-                const int wu = iu[0].prev, wd = iu[1].prev;
-                if (wu >= 0) { pu = load_side(wu); pu.m = su.m ^ su.f; }
-                if (wd >= 0) { pd = load_side(wd); pd.m = sd.m ^ sd.f; }
-                const float4 r0 = rec[g0];
-                float out[10];
-                const int cacb = zyz::block_table(out, su, sd, wu >= 0, pu, wd >= 0, pd, r0.x, r0.y, false);      // index 2 a_up + a_dn
-                float* bt = smem + lds.btab + ZYZL_TAB_FLOATS * b;
-                *reinterpret_cast<float4*>(bt) = make_float4(out[0], out[1], out[2], out[3]);
-                *reinterpret_cast<float4*>(bt + 4) = make_float4(out[4], out[5], out[6], out[7]);
-                *reinterpret_cast<float2*>(bt + 8) = make_float2(out[8], out[9]);
-                smem[lds.side + 16 * b + 7] = __int_as_float(su.m);
-                smem[lds.side + 16 * b + 15] = __int_as_float(sd.m);
-                *reinterpret_cast<float2*>(smem + lds.binfo + 2 * b) = make_float2(__int_as_float(cacb), out[0]);
-            } else {
-                const int q = w - K;
-                const ZyzSideInfo* iq = za.sides + 2 * K + q;
-                const int m = parity(iq->later), last = iq->prev;
-                const float4 r0 = rec[3 * q], r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
+        // ================= build B: pending-flip parities; side 0: the block's table; qubit: surface matrix, final left factor
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) {
+            Item& t = itm[s];
+            const int i = tid + 64 * s;
+            if (t.kind == 0) {
+                t.sd.m = parity_of(i);
+                if ((i & 1) == 0) {
+                    const int b = i >> 1;
+                    zyz::Side sd = load_side(i + 1), pu = t.sd, pd = sd;
+                    sd.m = parity_of(i + 1);
+                    const int wu = t.prev, wd = reinterpret_cast<const int*>(smem + lds.stat + 12 * (i + 1))[0];
+                    if (wu >= 0) { pu = load_side(wu); pu.m = t.sd.m ^ t.sd.f; }
+                    if (wd >= 0) { pd = load_side(wd); pd.m = sd.m ^ sd.f; }
+                    float out[10];
+                    t.cacb = zyz::block_table(out, t.sd, sd, wu >= 0, pu, wd >= 0, pd, ENT == 0 ? t.cs[3][0] : -1.f, ENT == 0 ? t.cs[3][1] : 0.f, false);
+                    t.d0 = out[0];
+                    float* bt = smem + lds.btab + ZYZL_TAB_FLOATS * b;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) *reinterpret_cast<float4*>(bt + 4 * k) = make_float4(out[2 * k], out[2 * k + 1], -out[2 * k + 1], out[2 * k + 1]);
+                    *reinterpret_cast<float2*>(bt + 16) = make_float2(out[8], out[9]);
+                }
+            } else if (t.kind == 1) {
+                const int q = i - 2 * K;
+                t.m = parity_of(i);
                 float sm[8];
-                zyz::surface_matrix(sm, r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, m);
+                zyz::surface_matrix(sm, t.cs[0][0], t.cs[0][1], t.cs[1][0], t.cs[1][1], t.cs[2][0], t.cs[2][1], t.m);
                 *reinterpret_cast<float4*>(smem + lds.surfm + 8 * q) = make_float4(sm[0], sm[1], sm[2], sm[3]);
                 *reinterpret_cast<float4*>(smem + lds.surfm + 8 * q + 4) = make_float4(sm[4], sm[5], sm[6], sm[7]);
                 float4 lf = make_float4(1.f, 0.f, 1.f, 0.f);
-                if (last >= 0) { const zyz::Side sl = load_side(last); lf = make_float4(sl.l0.re, sl.l0.im, sl.l1.re, sl.l1.im); }
+                if (t.prev >= 0) { const zyz::Side sl = load_side(t.prev); lf = make_float4(sl.l0.re, sl.l0.im, sl.l1.re, sl.l1.im); }
                 *reinterpret_cast<float4*>(smem + lds.lfin + 4 * q) = lf;
-                smem[lds.msf + q] = __int_as_float(m);
             }
         }
         lds_sync<1>();
@@ -381,10 +446,15 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
         {
             int b = 0;
+            ZlRaw nxt;
+            zl_load_raw<L, PL::v[0], PL::v[1]>(nxt, smem + lds.btab, ln);
             auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = decltype(jj)::value;
+                constexpr int J = decltype(jj)::value, JN = (J + 1) % LL;
+                const ZlRaw cur = nxt;
+                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * (b + 1 < K ? b + 1 : b), ln);
+                __builtin_amdgcn_sched_barrier(0);               // the reads stay here (the scheduler would sink them to their first use)
                 ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
-                zl_load(t, smem + lds.btab + ZYZL_TAB_FLOATS * b, ln);
+                zl_use(t, cur, ln);
                 zl_fwd<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, t);
                 gate_fence<L>();
                 b++;
@@ -424,13 +494,8 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
             acc[0] = tt.x; acc[1] = tt.y;
         }
         if (a.use_reg) {
-            for (int j = tid; j < P; j += THREADS) {
-                if (a.pkind[j]) {
-                    float sl;
-                    acc[2] += penalty_lds(smem, a.pen_kind, th[j], sl);
-                    psl[j] = a.r * sl;
-                }
-            }
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) acc[2] += itm[s].pval;
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
@@ -443,14 +508,19 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         if (it == 0) { first = regloss; best = regloss; }
         else if (regloss < best) { best = regloss; improved = true; }
         if (improved || a.hist_params) {
-            for (int j = tid; j < P; j += THREADS) {
-                const float t = th[j];
-                if (improved) a.out_params[(s_idx * 2 + 1) * P + j] = t;
-                if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + j] = t;
-            }
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = itm[s].pj[k];
+                    if (j < 0) continue;
+                    if (improved) out_best[j] = itm[s].th[k];
+                    if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + j] = itm[s].th[k];
+                }
         }
         if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         if (a.T == 0) break;
+        if (it + 1 == iters) break;                    // the last step's gradient would move the angles past the last evaluated iterate
 
         // ================= backward
         if (a.loss_kind == 2) {
@@ -466,10 +536,21 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
         {
             int b = K - 1;
+            ZlRaw nxt;
+            {
+                const int jt = (K - 1) % LL;                     // the last block's layer position
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jj)::value;
+                    if (J == jt) zl_load_raw<L, PL::v[2 * J], PL::v[2 * J + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * b, ln);
+                }, typename make_iseq<LL>::type{});
+            }
             auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = LL - 1 - decltype(jj)::value;
+                constexpr int J = LL - 1 - decltype(jj)::value, JN = (J + LL - 1) % LL;
+                const ZlRaw cur = nxt;
+                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * (b > 0 ? b - 1 : 0), ln);
+                __builtin_amdgcn_sched_barrier(0);
                 ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
-                zl_load(t, smem + lds.btab + ZYZL_TAB_FLOATS * b, ln);
+                zl_use(t, cur, ln);
                 float d8[8];
                 zl_bwd<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, cot, t, ln, d8);
                 reduce8_rows<true>(d8, smem + lds.sums + 32 * b, lane, dst_lane);
@@ -519,65 +600,55 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
         lds_sync<1>();
 
-        // ================= chain: one thread per side (its rotation angles; side 0 also the CP angle), one per qubit
-        for (int w = tid; w < 2 * K + NQ; w += THREADS) {
-            if (w < 2 * K) {
-                const int b = w >> 1, side = w & 1, g0 = NS + per_block * b, kx = 3 * side;
-                const float px = slab_sum(lds.sums, b, kx), py = slab_sum(lds.sums, b, kx + 1), pz = slab_sum(lds.sums, b, kx + 2);
-                const zyz::Side sd = load_side(w);
-                float gpart[8];
-                zyz::chain_side<ROT>(gpart, px, py, pz, sd, block_rec(g0), NR, side);
+        // ================= chain: the gradients of the item's own angles, into the owner's registers
 #pragma unroll
-                for (int i = 0; i < (ROT ? (ROT & 15) : 8); i++) {
-                    if (i < zyz::rotc_n<ROT>(NR)) gw[g0 + 1 + 2 * i + side] = gpart[i];
-                }
-                const bool is_cp = ROT ? ((ROT >> 16) & 3) == 0 : (__float_as_int(rec[g0].z) & 15) == OP_CP;
-                if (side == 0 && is_cp) {
+        for (int s = 0; s < NSLOT; s++) {
+            Item& t = itm[s];
+            const int i = tid + 64 * s;
+            if (t.kind == 0) {
+                const int b = i >> 1, side = i & 1, kx = 3 * side;
+                const float px = slab_sum(lds.sums, b, kx), py = slab_sum(lds.sums, b, kx + 1), pz = slab_sum(lds.sums, b, kx + 2);
+                auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
+                    const int k = (idx - 1) >> 1;
+                    c = t.cs[k][0]; sn = t.cs[k][1]; kind = 0;
+                };
+                float gpart[4];
+                zyz::chain_side<ROT>(gpart, px, py, pz, t.sd, rrec, NR, side);
+#pragma unroll
+                for (int k = 0; k < NR; k++) t.g[k] = gpart[k];
+                if (ENT == 0 && side == 0) {
                     float pzq[2];
 #pragma unroll
-                    for (int s = 0; s < 2; s++) {
-                        const int wp = za.sides[w + s].prev, q = za.sides[w + s].qubit;
-                        pzq[s] = wp < 0 ? slab_sum(lds.gsurf, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, wp >> 1, 3 * (wp & 1) + 2);
+                    for (int sd2 = 0; sd2 < 2; sd2++) {
+                        const int* st = reinterpret_cast<const int*>(smem + lds.stat + 12 * (i + sd2));
+                        const int wp = st[0], q = st[1];
+                        pzq[sd2] = wp < 0 ? slab_sum(lds.gsurf, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, wp >> 1, 3 * (wp & 1) + 2);
                     }
-                    const float2 bi = *reinterpret_cast<const float2*>(smem + lds.binfo + 2 * b);
-                    gw[g0] = zyz::chain_cp(slab_sum(lds.sums, b, 6), pzq[0], pzq[1], __float_as_int(bi.x), bi.y);
+                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, b, 6), pzq[0], pzq[1], t.cacb, t.d0);
                 }
-            } else {
-                const int q = w - 2 * K;
+            } else if (t.kind == 1) {
+                const int q = i - 2 * K;
                 float pv[3], gs[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) pv[k] = slab_sum(lds.gsurf, (3 * q + k) >> 3, (3 * q + k) & 7);
-                const float4 r1 = rec[3 * q + 1], r2 = rec[3 * q + 2];
-                zyz::chain_surface(gs, pv[0], pv[1], pv[2], __float_as_int(smem[lds.msf + q]), r1.x, r1.y, r2.x, r2.y);
+                zyz::chain_surface(gs, pv[0], pv[1], pv[2], t.m, t.cs[1][0], t.cs[1][1], t.cs[2][0], t.cs[2][1]);
 #pragma unroll
-                for (int k = 0; k < 3; k++) gw[3 * q + k] = gs[k];
+                for (int k = 0; k < 3; k++) t.g[k] = gs[k];
             }
         }
-        lds_sync<1>();
-
-        // ================= Adam (optax 0.1.1 scale_by_adam + scale(-lr)), owners only
-        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
-        for (int j = tid; j < P; j += THREADS) {
-            float g = gw[a.pgate[j]];
-            if (a.use_reg && a.pkind[j]) g += psl[j];
-            if (frozen && frozen[j]) continue;
-            const float m = fmaf(a.b1, mm[j], a.omb1 * g);
-            const float v = fmaf(a.b2, vv[j], a.omb2 * (g * g));
-            mm[j] = m; vv[j] = v;
-            const float t = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), th[j]);
-            th[j] = t;
-            publish(j, t);
-        }
-        lds_sync<1>();
+        // no barrier: the next step's owner phase reads only this lane's registers; its LDS writes (side records, flip words) touch
+        // what this phase did not read after ... the sums slabs are rewritten only by the next backward sweep
     }
 
-    // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370); argmin, CZ count, entry-loss flag
+    // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370); argmin, CZ count, entry-loss flag.  Every CP
+    // angle is read back by the lane that wrote it.
     const int bi = (best < first) ? 1 : 0;
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int j = tid; j < P; j += THREADS) {
-        if (a.pkind[j]) {
-            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j];
-            const float t1 = a.out_params[(s_idx * 2 + 1) * P + j];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const int j = itm[s].pj[3];
+        if (j >= 0) {
+            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j], t1 = out_best[j];
             float sl;
             if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
             acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);
@@ -596,9 +667,9 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     }
 }
 
-template <int NQ, int ROT, int... UD>
+template <int NQ, int ROT, int NSLOT, int... UD>
 __global__ __launch_bounds__(256, 1) void k_cp_zyzl(const ZyzlArgs za) {
-    zyzl_body<NQ, ROT, UD...>(za);
+    zyzl_body<NQ, ROT, NSLOT, UD...>(za);
 }
 
 }  // namespace cpf

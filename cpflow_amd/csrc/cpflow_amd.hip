@@ -591,38 +591,41 @@ bool try_zyz(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream,
 
 // ---- ZYZ form on the gate-by-gate layout (cpf_zyzl.h): one wave per sample, 4 and 5 qubits, CP or CZ blocks,
 // layer-specialised (ahead of time for config 4's relabelled chain, at run time otherwise).  CPF_ZYZL=0|1 switches it.
-cpf_jit::Spec zyzl_jit_spec(int nq, int rot, const std::vector<int>& ud) {
-    cpf_jit::Spec spec{"cpf_zyzl.h", cpf_jit::body_expr("zyzl_body", {nq, rot}, ud), 256};      // up to four one-wave samples per workgroup
+int zyzl_slots(const cpf_plan* plan) { return (2 * plan->K + plan->n + 63) / 64; }          // items (sides + qubits) per lane
+cpf_jit::Spec zyzl_jit_spec(int nq, int rot, int nslot, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyzl.h", cpf_jit::body_expr("zyzl_body", {nq, rot, nslot}, ud), 256};      // up to four one-wave samples per workgroup
     spec.arg = "cpf::ZyzlArgs";
     spec.min_waves = 1;
     spec.flags = {CPF_DENSE_MLLVM_FLAGS};
     return spec;
 }
 bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
-    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw != 0 || plan->n != plan->NQ || plan->NQ < 4 || plan->NQ > 5) return false;
-    if (plan->K < 1 || plan->K > cpf::ZYZ_MAX_BLOCKS || plan->n_rot < 1 || plan->n_rot > 8 || plan->entangler == CPF_ENTANGLER_CX) return false;
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw != 0 || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
+    if (plan->K < 1 || zyzl_slots(plan) > 4 || plan->n_rot < 1 || plan->n_rot > 3 || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     const TuneVal e = tuning("CPF_ZYZL");
-    return e ? e[0] != '0' : true;
+    return e ? e[0] != '0' : plan->NQ >= 4;          // 3 qubits (one amplitude per lane): on request (A/B against the two-ended kernel)
 }
 bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
     const int nq = plan->NQ, rot = dense_rot_code(plan), which = labelling_for(plan, a_in.mode, lw);
-    const bool have_aot = cpf_zyzl_has_aot(nq, rot, plan->layer_ud);
+    const int nslot = zyzl_slots(plan);
+    const bool have_aot = cpf_zyzl_has_aot(nq, rot, nslot, plan->layer_ud);
     const cpf_jit::Kernel* jk = nullptr;
     if (!have_aot) {
         if (!plan->use_jit) return false;
-        jk = &cpf_jit::get(plan->device, zyzl_jit_spec(nq, rot, plan->layer_ud));
+        jk = &cpf_jit::get(plan->device, zyzl_jit_spec(nq, rot, nslot, plan->layer_ud));
         if (!jk->fn) {
             plan->jit_note = jk->error;
             if (jk->error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", jk->error.c_str()); return true; }
             return false;
         }
     }
-    const size_t lds1 = (size_t)cpf::ZyzlLds(a_in.P, a_in.G, plan->K, nq).total * sizeof(float);
+    const size_t lds1 = (size_t)cpf::ZyzlLds(plan->K, nq).total * sizeof(float);
     if (lds1 > (size_t)plan->lds_per_cu) return false;
     cpf::KArgs a = a_in;
     a.group = layered_group(plan, lw, S, lds1);
+    if (nq == 3 && S > plan->num_cu) a.group = 4;          // four waves of a workgroup land on the CU's four SIMDs (cpf_layered.h)
     const size_t lds = lds1 * a.group;
     if ((*rc = zyz_sides(plan, which))) return true;
     const cpf::ZyzlArgs za{a, plan->zyz_sides[which].as<cpf::ZyzSideInfo>(), plan->K, plan->n_rot};
@@ -630,7 +633,7 @@ bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStre
     hipError_t e = hipSuccess;
     const std::string tail = std::string(" waves=1") + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
     if (have_aot) {
-        cpf_zyzl_launch_aot(nq, rot, plan->layer_ud, za, grid, block, lds, stream, &e);
+        cpf_zyzl_launch_aot(nq, rot, nslot, plan->layer_ud, za, grid, block, lds, stream, &e);
         plan->variant = "zyzl/aot" + tail;
     } else {
         if (!module_lds_opt_in(jk->fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the ZYZ-form kernel"; return false; }
@@ -823,6 +826,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     }
     // 0. a shipped 3-qubit kernel specialised on the block count; 1. ahead-of-time layered kernel (3 qubits, the
     // reference's own layers); 2. runtime-specialised layered kernel; 3. generic per-gate kernel
+    { const TuneVal e = tuning("CPF_ZYZL"); if (e && e[0] == '1' && plan->NQ == 3 && try_zyzl(plan, a, lw, S, stream, &rc)) return rc; }
     if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_zyz(plan, a, S, stream, &rc)) return rc;
@@ -1186,8 +1190,8 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     }
     const int lw = choose_lw(&pl, num_samples);
     select_labelling(&pl, labelling_for(&pl, cpf::MODE_OPTIMIZE, lw));
-    if (zyzl_wanted(&pl, cpf::MODE_OPTIMIZE, lw) && !cpf_zyzl_has_aot(pl.NQ, dense_rot_code(&pl), pl.layer_ud)) {
-        const cpf_jit::Spec spec = zyzl_jit_spec(pl.NQ, dense_rot_code(&pl), pl.layer_ud);
+    if (zyzl_wanted(&pl, cpf::MODE_OPTIMIZE, lw) && !cpf_zyzl_has_aot(pl.NQ, dense_rot_code(&pl), zyzl_slots(&pl), pl.layer_ud)) {
+        const cpf_jit::Spec spec = zyzl_jit_spec(pl.NQ, dense_rot_code(&pl), zyzl_slots(&pl), pl.layer_ud);
         const cpf_jit::Code code = cpf_jit::build(spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
         if (int rc = precompile_landed(code, spec.body)) return rc;

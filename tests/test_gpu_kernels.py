@@ -849,7 +849,8 @@ ZYZL_CASES = [
     ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', 'jit'),              # 5 qubits: 16 amplitudes per lane, one lane qubit
     ([[i, j] for i in range(5) for j in range(i + 1, 5)], 13, 'xz', 'cp', 'jit'),      # 5 qubits all-to-all (paper/results/benchmarks)
     ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cz', 'jit'),                 # fixed entangler, one letter
-    ([[1, 0], [0, 1], [2, 3]], 7, 'zyxz', 'cp', 'jit'),                      # both qubits of a block on lanes (after relabelling: 2, 3); 4 letters
+    ([[1, 0], [0, 1], [2, 3]], 7, 'zyx', 'cp', 'jit'),                       # both qubits of a block on lanes (unrelabelled: 0, 1)
+    ([[0, 1], [1, 2], [2, 3], [3, 4]], 36, 'xyz', 'cp', 'jit'),              # 77 items: two per lane
     ([[0, 1], [3, 2]], 1, 'xyz', 'cp', 'jit'),                               # a single block, untouched qubits
 ]
 

@@ -212,22 +212,27 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
 
 
-def test_block_count_specialised_kernels_per_regime():
+def test_block_count_specialised_kernels_per_regime(tmp_path):
     """3 qubits: the K-specialised two-ended kernel a launch would look up, by samples per CU (cpflow_amd.hip
     jit_candidates with k_mode 1; MSTORE = form + 4 K + the balanced-cut bit 17): one sample per CU -> stored states and the
     balanced cut, two -> that with both samples in one workgroup, a few per CU -> stored states, saturated -> un-apply.  All of them are in the shipped cache for the block
     counts of an adaptive search (build.precompile_shapes)."""
     import json
+    import shutil
     import subprocess
     import sys
+    if not os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        pytest.skip('no hipcc: the run-time specialised kernels cannot be built here')
     chain3 = [[0, 1], [1, 2]]
+    cache = tmp_path / 'cache'                 # a checkout whose shipped cache was not built yet compiles them - here, not into ~/.cache
+    cache.mkdir(mode=0o700)
 
     def kernels(K, S):
         code = ("import json, sys; from cpflow_amd.build import _precompile_one; "
                 f"print(json.dumps(_precompile_one({chain3!r}, 'xyz', {K}, {S}, tuning={{'CPF_JIT_K': '1'}})))")
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ), capture_output=True, text=True, cwd=ROOT)
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CPF_JIT_CACHE=str(cache)), capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr
-        return json.loads(r.stdout.strip().splitlines()[-1])[0].replace('[built]', '[cached]')      # a checkout whose cache was not built yet compiles them
+        return re.sub(r'jit\(\w+\)', 'jit(hipcc)', json.loads(r.stdout.strip().splitlines()[-1])[0].replace('[built]', '[cached]'))
     assert kernels(14, 100).startswith(f'split/jit(hipcc) waves=2 states K lone [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (2 << 16)}, 0, 1, 1, 2>')
     assert kernels(14, 512).startswith(f'split/jit(hipcc) waves=2 states K pairs=2 [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (3 << 16)}, 0, 1, 1, 2>')
     assert kernels(14, 700).startswith(f'split/jit(hipcc) waves=2 states K [cached] cpf::split_body<8451, 1, {2 + 4 * 14}, 0, 1, 1, 2>')
@@ -325,3 +330,12 @@ def test_generated_dense_asm_header_is_current(tmp_path):
         # operand 8 + index: forward G[4 i + j], adjoint G[4 j + i]
         used = sorted({int(l.split('%')[2].split(',')[0]) for l in g})
         assert used == list(range(8, 24))
+
+
+def test_generated_zyz_asm_header_is_current():
+    """cpflow_amd/csrc/cpf_zyz_asm.h is generated (tools/gen_zyz_asm.py): the committed file must be what the generator emits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_zyz_asm', os.path.join(ROOT, 'tools', 'gen_zyz_asm.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(os.path.join(ROOT, 'cpflow_amd', 'csrc', 'cpf_zyz_asm.h')).read() == gen.render()

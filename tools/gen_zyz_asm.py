@@ -94,10 +94,12 @@ def backward(first):
         lines += [h02[0], h02[1], h13[0], h13[1]]
         l01, l23 = stage(x[0], x[1], u[0], u[1], tt, False, -1), stage(x[2], x[3], u[2], u[3], tt, False, -1)
         lines += [l01[0], l23[0], l01[1], l23[1]]
-    lines.append(acc(CC, c[3], p[3], True, False, first))
     for x in (p, c):
         m1, m3, m2 = cmul(x[1], u[1], d[1], x[1], True), cmul(x[3], u[3], d[3], x[3], True), cmul(x[2], u[2], d[2], x[2], True)
-        lines += [m1[0], m3[0], m2[0], f'v_pk_mul_f32 {x[0]}, {sd}, {x[0]} op_sel_hi:[0,1]', m1[1], m3[1], m2[1]]
+        lines += [m1[0], m3[0], m2[0]]
+        if x is p:                # the |11> sum reads c_3 (written three instructions ago) and p_3 before conj(d_3) lands in it
+            lines.append(acc(CC, c[3], p[3], True, False, first))
+        lines += [f'v_pk_mul_f32 {x[0]}, {sd}, {x[0]} op_sel_hi:[0,1]', m1[1], m3[1], m2[1]]
     assert len(lines) == 51
     return lines
 
