@@ -168,6 +168,9 @@ def main():
     ap.add_argument('--samples-per-gpu', type=int, default=None, help="override the configuration's per-GPU sample count")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the extra.other_configs block of the cfg2 line')
+    ap.add_argument('--strong-ref', action='store_true',
+                    help='N > 1: after the timed region rank 0 also runs ALL samples of the job on its one GPU (the strong-scaling '
+                         'reference), so that the line carries weak AND strong efficiency')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -236,6 +239,21 @@ def main():
     out, summary = step()
     fence()
 
+    # strong-scaling reference (opt-in): the whole job's samples on rank 0's GPU alone, same step, three timed passes
+    strong_ref = None
+    if args.strong_ref and world > 1:
+        if rank == 0:
+            def step_all():
+                return eng.optimize(eng.initial_angles(seed, S_total, 0, S_total))
+            step_all()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step_all()
+            torch.cuda.synchronize()
+            strong_ref = {'samples': S_total, 'ms_per_step_one_gpu': (time.perf_counter() - t1) / 3 * 1e3, 'kernel': eng.last_variant()}
+        dist.barrier()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if world == 1 or dist.get_backend() == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -267,13 +285,19 @@ def main():
                                  f'vector peak; kernel {k_ms:.3f} ms per launch (mean of {len(k_all)} timed launches, HIP '
                                  f'events on the launch stream; median {sorted(k_all)[len(k_all) // 2]:.3f}), '
                                  f'{flops:.0f} flop/sample-step; traffic = HBM bytes per launch from the stored rocprofv3 '
-                                 '--pmc passes named in traffic_source (not measured in this run)',
+                                 '--pmc passes named in traffic_source (not measured in this run); flop/sample-step is SURVEY '
+                                 '8(d)\'s algorithmic count (one dense 4x4 per block and pass) whatever algebra the kernel runs - the '
+                                 'ZYZ-form kernels (zyz/, zyzl/) execute fewer (DESIGN.md section 4)',
                          'kernel': eng.last_variant()},
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes,
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,
                     'frac': alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         line['distributed'] = dist_info
+        if strong_ref:
+            # strong efficiency = t(1 GPU, all samples) / (N x t(N GPUs, all samples)); the weak one is the driver's from its per-N values
+            strong_ref['strong_scaling_efficiency'] = strong_ref['ms_per_step_one_gpu'] / (n_gpus * line['ms_per_step'])
+            line['strong_ref'] = strong_ref
         if n_gpus == 1 and args.config == 'cfg2' and not args.no_other_configs:
             line['extra'] = {'other_configs': other_configs(workloads, TemplateEngine, torch)}
         if not args.no_cpu_baseline and n_gpus == 1:

@@ -132,9 +132,9 @@ int32_t cpf_unitary_device(const cpf_plan* plan, int64_t num_samples, const floa
 /* Duration in ms of the last cpf_optimize_device kernel of this plan, measured with HIP events
  * on the launch stream (blocks until that kernel has finished). */
 int32_t cpf_plan_last_kernel_ms(cpf_plan* plan, float* out_ms);
-/* Which kernel the last launch on this plan used: "split/aot ...", "layered/aot waves=N", "dense/aot waves=N",
- * "layered/jit(hipcc) waves=N" / "(hiprtc)" (runtime-specialised: the compiler that produced the code object, whether
- * it was built in this process or came from a cache) or "generic/aot waves=N (reason)". */
+/* Which kernel the last launch on this plan used: "split/aot ...", "zyz/aot waves=N", "zyzl/aot waves=1", "layered/aot waves=N",
+ * "dense/aot waves=N", "<family>/jit(hipcc) ..." / "(hiprtc)" (runtime-specialised: the compiler that produced the code object,
+ * whether it was built in this process or came from a cache) or "generic/aot waves=N (reason)". */
 int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
 
 /* ---- runtime specialisation (no counterpart in the reference: jax.jit compiles on first call, optimization.py:361-363).
@@ -145,11 +145,11 @@ int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
  * <library dir>/jit_cache).  Returns the number of kernels (>= 0; 0 = the shape runs on ahead-of-time kernels only) and
  * one line per kernel in buf, or a negative error code. */
 int32_t cpf_jit_compiles(void);
-/* Kernel-selection switches for tests and A/B measurements (no counterpart in the reference): name is one of "CPF_SPLIT",
- * "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP", "CPF_DENSE", "CPF_DENSE_LW",
- * "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_RELABEL", "CPF_FORCE_GENERIC", "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"; value
- * NULL restores the default.  Process-wide; plans read the switches when they are created and at every launch.  The
- * release library does not read these names from the environment.  Returns 0, or -1 for an unknown name. */
+/* Diagnostics hook, not part of what a cpflow binding needs: forces a kernel family / variant for tests and A/B measurements
+ * (the names and their values are listed in tools/README.md; value NULL restores the default).  Process-wide and thread-safe;
+ * a plan reads the switches when it is created and at every launch, and caches what it derived from them (per-block tables),
+ * so set them BEFORE creating the plan they should apply to.  The release library reads none of them from the environment.
+ * Returns 0, or -1 for an unknown name. */
 int32_t cpf_set_tuning(const char* name, const char* value);
 int32_t cpf_jit_precompile(const cpf_problem* problem, int64_t num_samples, char* buf, size_t size);
 

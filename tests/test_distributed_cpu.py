@@ -1,4 +1,4 @@
-"""CPU: the N>1 path (sample sharding + the one all-gather) with gloo, world_size 2 and 3."""
+"""CPU: the N>1 path (sample sharding + the one all-gather) with gloo, world sizes 2, 3, 4 and 8."""
 import os
 import socket
 
@@ -22,13 +22,14 @@ def test_shard_ranges_partition_all_samples():
             assert seen == list(range(S))
 
 
-def _worker(rank, size, port, S, q):
+def _worker(rank, size, port, S, q, P=5):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=size)
     try:
         first, count = distributed.shard_range(S, rank, size)
         g = torch.Generator().manual_seed(1234)
-        full = {'params': torch.rand(S, 2, 5, generator=g), 'regloss': torch.rand(S, 2, generator=g),
+        full = {'params': torch.rand(S, 2, P, generator=g), 'regloss': torch.rand(S, 2, generator=g),
                 'cz': torch.randint(0, 30, (S,), generator=g, dtype=torch.int32),
                 'passed': torch.rand(S, generator=g) > 0.5}
         local = {k: v[first:first + count] for k, v in full.items()}
@@ -44,15 +45,21 @@ def _worker(rank, size, port, S, q):
 
 # (3, 2), (4, 5): some ranks own no sample (shard_range hands out empty shards whenever ceil(S/R)(R-1) >= S,
 # e.g. the README's num_samples=10 on 8 ranks); they must still take part in the collective
-@pytest.mark.parametrize('size,S', [(2, 10), (2, 7), (3, 8), (3, 2), (4, 5)])
-def test_gather_equals_single_rank(size, S):
+# world size 8 = the north star's node: the README's example (10 samples: ranks 5, 6, 7 own nothing, rank 4 two), and the
+# splits of BASELINE configs 3 and 5 (4096 = 8 x 512 rows of 121 angles, 8192 = 8 x 1024 rows of 438: the real slab widths,
+# rows gathered in global sample order)
+@pytest.mark.parametrize('size,S,P', [(2, 10, 5), (2, 7, 5), (3, 8, 5), (3, 2, 5), (4, 5, 5), (8, 10, 5), (8, 4096, 121), (8, 8192, 438)])
+def test_gather_equals_single_rank(size, S, P):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    if size == 8:
+        per = [distributed.shard_range(S, r, 8)[1] for r in range(8)]
+        assert per == ([2, 2, 2, 2, 2, 0, 0, 0] if S == 10 else [S // 8] * 8)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, size, port, S, q)) for r in range(size)]
+    procs = [ctx.Process(target=_worker, args=(r, size, port, S, q, P)) for r in range(size)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
