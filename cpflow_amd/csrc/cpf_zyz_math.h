@@ -39,9 +39,13 @@ CPF_ZHD C2 c2(float re, float im) { C2 r; r.re = re; r.im = im; return r; }
 CPF_ZHD C2 cmul(C2 a, C2 b) { return c2(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
 CPF_ZHD C2 cconj(C2 a) { return c2(a.re, -a.im); }
 CPF_ZHD C2 cscale(C2 a, float s) { return c2(a.re * s, a.im * s); }
+// 1 / sqrt(x).  The hardware approximation (1 ulp, and not centred: 60 blocks of it cost config 5's unitary 1e-5 of its norm)
+// gets one Newton step, after which only the roundings of the last two operations remain.
 CPF_ZHD float zrsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rsqf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-(x * y), 0.5f * y, 0.5f);
+    return __builtin_fmaf(y, e, y);
 #else
     return 1.0f / std::sqrt(x);
 #endif
@@ -88,12 +92,14 @@ CPF_ZHD Side side_build(const Rec& rec, int n_rot, int side) {
         const float tmp = n2; n2 = m2; m2 = tmp;
     }
     const float ip = zrsqrt(n2);
-    sd.sc = n2 * ip;
     sd.l0 = cscale(p, ip);
     const bool ok = m2 > 1e-30f;
     const float iq = ok ? zrsqrt(m2) : 0.f;
     sd.l1 = ok ? cscale(q, iq) : c2(1.f, 0.f);
     sd.t = ok ? (m2 * iq) * ip : 0.f;
+    // the scale from the tangent that is actually applied: sc [[1, -t], [t, 1]] is then unitary to rounding whatever the
+    // roundings of (p, q) were (sc = |p| would inherit their |p|^2 + |q|^2 - 1)
+    sd.sc = zrsqrt(1.f + sd.t * sd.t);
     return sd;
 }
 

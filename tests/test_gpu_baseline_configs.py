@@ -131,7 +131,18 @@ def _ks_two_sample_p(a, b):
     return float(ks_2samp(a, b).pvalue)
 
 
-def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_tol, expect_variant=None, S_total=None, same_flag_min=0.95):
+_ORACLE_RUNS = {}          # (workload, samples, seed) -> the float32 oracle's run: several kernel variants are compared with the same one
+
+
+def _oracle_run(wl, init, T):
+    key = (wl.name, init.shape[0], int(wl.seed), T)
+    if key not in _ORACLE_RUNS:
+        orc = Oracle(wl.layer, wl.num_cp_gates, wl.target, wl.rotation_gates, num_gd_iterations=T, r=wl.r)
+        _ORACLE_RUNS[key] = orc.run(init, np.float32, nthreads=int(orc.lib.cpfo_max_threads()))
+    return _ORACLE_RUNS[key]
+
+
+def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_tol, expect_variant=None, S_total=None, same_flag_min=0.95, pooled=None):
     """One BASELINE configuration at full length (S samples x 2000 iterations) on the kernel and on the float32 oracle
     (same initial angles, all host cores).  Individual runs are chaotic (lr 0.1 for 2000 steps), so the comparison is
     statistical: it would catch a systematic drift from fast_sincos, the rcp / sqrt Adam step, -fno-signed-zeros, a wrong
@@ -147,13 +158,14 @@ def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_to
     variant = eng.last_variant()
     if expect_variant:
         assert variant.startswith(expect_variant), variant
-    orc = Oracle(wl.layer, wl.num_cp_gates, wl.target, wl.rotation_gates, num_gd_iterations=T, r=wl.r)
-    ref = orc.run(init.cpu().numpy(), np.float32, nthreads=int(orc.lib.cpfo_max_threads()))
+    ref = _oracle_run(wl, init.cpu().numpy(), T)
     pg, po = out['passed'], ref['passed'].astype(bool)
+    if pooled is not None:                                    # several seeds of one problem: the caller asserts on the pooled counts
+        pooled.append((int(pg.sum()), int(po.sum()), S, out['regloss'][:, 1].copy(), ref['regloss'][:, 1].copy()))
     p = (pg.sum() + po.sum()) / (2 * S)
     sigma = np.sqrt(2 * S * p * (1 - p))                      # sd of the difference of two binomial counts
     print(f'[{wl.name} {variant}] passed: kernel {pg.sum()} oracle {po.sum()} (3 sigma = {3 * sigma:.1f}); same flag {np.mean(pg == po):.3f}')
-    assert abs(int(pg.sum()) - int(po.sum())) <= max(3 * sigma, 1)
+    assert abs(int(pg.sum()) - int(po.sum())) <= max((3 if pooled is None else 4) * sigma, 1)      # pooled runs: the 3-sigma bar is on the pool
     assert np.mean(pg == po) >= same_flag_min
     both = pg & po
     if both.sum() >= 50:
@@ -194,19 +206,22 @@ def test_config2_unbiased_against_float32_oracle():
     _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(6, 14)), 0.85, 2e-4, 5e-5, 'split/aot')
 
 
-def test_config4_unbiased_against_float32_oracle():
-    """Config 4 at full size (4-qubit QFT, 2048 samples x 2000 iterations) on the relabelled one-wave gate-by-gate
-    kernel.  4-qubit runs are more chaotic than 3-qubit ones (tests/test_gpu_synthesis.py, fixture toff4_star_t14:
-    independent roundings of the oracle agree with each other on 84-86 % of the per-sample CZ counts)."""
+@pytest.mark.parametrize('kernel', ['zyzl', 'layered'])
+def test_config4_unbiased_against_float32_oracle(kernel, tune):
+    """Config 4 at full size (4-qubit QFT, 2048 samples x 2000 iterations) on the relabelled one-wave kernels - the ZYZ form
+    (cpf_zyzl.h, the default) and the gate-by-gate kernel it replaced - against ONE float32 oracle run.  4-qubit runs are more
+    chaotic than 3-qubit ones (tests/test_gpu_synthesis.py, fixture toff4_star_t14: independent roundings of the oracle agree
+    with each other on 84-86 % of the per-sample CZ counts)."""
     from cpflow_amd import workloads
     wl = workloads.CONFIGS['cfg4']
-    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(14, 30)), 0.5, 1e-3, 1e-3)
+    tune.set('CPF_ZYZL', '1' if kernel == 'zyzl' else '0')
+    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(14, 30)), 0.5, 1e-3, 1e-3, kernel + '/aot waves=1')
 
 
 def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
     """The 5-qubit benchmark problem of paper/results/benchmarks/res_4gt13_91 trial 99 (chain, 'xyz', 86 blocks, 617
-    angles, its stored target, seed and r): all 1000 samples over 2000 iterations on the relabelled
-    one-wave layered kernel from the shipped cache against the float32 oracle.  The stored run itself used older penalty
+    angles, its stored target, seed and r): 2 x 500 samples over 2000 iterations on the relabelled
+    one-wave ZYZ-form kernel from the shipped cache against the float32 oracle.  The stored run itself used older penalty
     constants, so it pins loss and initial angles only (tests/test_gpu_synthesis.py); this is the full-length pin of the
     5-qubit kernel."""
     monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
@@ -217,12 +232,21 @@ def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
         r, seed, num_gd_iterations = float(g['r']), int(g['seed']), 2000
     # 86 blocks x 2000 steps on 5 qubits: which of the ~8 % of the runs end below entry_loss is decided by rounding (kernel and
     # oracle agree on 89 % of the flags; independent draws at this rate would agree on 86 %), so the per-sample bars are low
-    # and the distribution-level ones carry the test
-    _unbiased_against_float32_oracle(Trial, int(g['num_samples']), list(range(40, 80, 4)), 0.0, 2e-3, 2e-3, 'layered/jit(hipcc) waves=1',
-                                     same_flag_min=0.8)
+    # and the distribution-level ones carry the test.  Two seeds (the stored one and a second: round 3 saw 88 against 67 passes
+    # on the stored seed alone, 1.8 sigma) of 500 samples each; the pass counts are asserted on the pool.
+    pooled = []
+    for seed in (Trial.seed, Trial.seed + 1):
+        Trial.seed = seed
+        _unbiased_against_float32_oracle(Trial, 500, list(range(40, 80, 4)), 0.0, 3e-3, 3e-3, 'zyzl/jit(hipcc) waves=1', same_flag_min=0.8, pooled=pooled)
+    kp, op, n = sum(p[0] for p in pooled), sum(p[1] for p in pooled), sum(p[2] for p in pooled)
+    rate = (kp + op) / (2 * n)
+    sigma = np.sqrt(2 * n * rate * (1 - rate))
+    ks_p = _ks_two_sample_p(np.concatenate([p[3] for p in pooled]), np.concatenate([p[4] for p in pooled]))
+    print(f'pooled over {len(pooled)} seeds: kernel {kp} oracle {op} passes of {n} (3 sigma = {3 * sigma:.1f}); KS p = {ks_p:.3f}')
+    assert abs(kp - op) <= 3 * sigma and ks_p > 1e-3
 
 
-@pytest.mark.parametrize('name,variant,same_flag_min', [('raw_toff4_star_t14', 'layered/jit(hipcc) waves=4', 0.9), ('raw_4gt10_xz_t30', 'layered/jit(hipcc) waves=1', 0.98)])
+@pytest.mark.parametrize('name,variant,same_flag_min', [('raw_toff4_star_t14', 'layered/jit(hipcc) waves=4', 0.9), ('raw_4gt10_xz_t30', 'zyzl/jit(hipcc) waves=1', 0.98)])
 def test_stored_tutorial_and_paper_shapes_unbiased_against_float32_oracle(name, variant, same_flag_min, monkeypatch):
     """The two remaining kernel variants the reference's stored trials exercise, at full length against the float32 oracle:
     the four-waves-per-sample layout (4-qubit star of tutorial/results/toff4_star trial 14: 29 blocks, 500 samples - fewer

@@ -145,7 +145,8 @@ def test_runtime_specialised_kernel_matches_generic_and_oracle(layer, K, rot, lw
     frozen[1::2, ::5] = 1
     tune.set('CPF_LW', lw)
     tune.set('CPF_SPLIT', '0')          # the two-ended 3-qubit kernel has its own test below
-    tune.set('CPF_DENSE', '0')          # ... and so has the dense-block kernel
+    tune.set('CPF_DENSE', '0')          # ... and so have the dense-layout kernels
+    tune.set('CPF_ZYZL', '0')           # ... and the ZYZ form of this layout (this test pins the gate-by-gate kernel, its fallback)
     outs = {}
     for jit in ('1', '0'):
         tune.set('CPF_JIT', jit)
@@ -335,9 +336,10 @@ def test_two_qubit_problems_run_on_the_three_qubit_kernels(ent, layer, K, rot, S
     assert (hp[:, :, 2::3] == theta[:, None, 2::3]).all() and (hp[:, -1, 0::3] != theta[:, 0::3]).any()
 
 
+@pytest.mark.parametrize('kernel', ['zyzl', 'layered'])
 @pytest.mark.parametrize('layer,K,rot', [([[0, 1], [0, 2], [0, 3]], 7, 'xyz'), ([[0, 1], [1, 2], [2, 3], [3, 4]], 9, 'xz'),
                                          ([[2, 1], [1, 3], [1, 0]], 6, 'zy')])
-def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch, tune):
+def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, kernel, monkeypatch, tune):
     """With one wave per sample the 4- and 5-qubit kernels keep their last row qubits in registers, so the library relabels
     the problem's qubits (most-used last; placements, gate program, target rows and columns) for those launches.
     Parameters, the unitary entry point and every result stay in the problem's own labels: same history as the float64
@@ -349,11 +351,12 @@ def test_qubit_relabelling_changes_nothing_but_speed(layer, K, rot, monkeypatch,
     theta = np.random.default_rng(2).uniform(0, 2 * np.pi, size=(S, orc.P)).astype(np.float32)
     ref = orc.run(theta[:6], np.float64, keep_history=True)
     res = {}
+    tune.set('CPF_ZYZL', '1' if kernel == 'zyzl' else '0')          # both one-wave kernels of this layout read the relabelled problem
     for relabel in ('1', '0'):
         tune.set('CPF_RELABEL', relabel)
         eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.003)
         out = {k: v.cpu().numpy() for k, v in eng.optimize(theta, keep_history=True).items()}
-        assert eng.last_variant().startswith('layered/jit') and eng.last_variant().endswith('waves=1'), eng.last_variant()
+        assert eng.last_variant().startswith(kernel + '/jit') and eng.last_variant().endswith('waves=1'), eng.last_variant()
         assert np.abs(out['history_regloss'][:6, 0] - ref['history_loss'][:, 0]).max() < 5e-6
         assert np.abs(out['history_regloss'][:6] - ref['history_loss']).max() < 5e-5
         assert np.abs(out['history_params'][:6] - ref['history_params'])[:, :3].max() < 1e-4
@@ -580,6 +583,7 @@ def test_grouped_one_wave_launches_are_bit_identical(layer, K, rot, S, tune):
     target = _rand_unitary(n, 51)
     tune.set('CPF_LW', '0')
     tune.set('CPF_DENSE', '0')
+    tune.set('CPF_ZYZL', '0')           # (test_zyzl_grouped_launches_are_bit_identical is the same test for the ZYZ form)
     res = {}
     for g in ('1', '2', '4', None):
         tune.unset('CPF_GROUP') if g is None else tune.set('CPF_GROUP', g)
@@ -650,7 +654,7 @@ def test_shipped_jit_cache_needs_no_compiler(monkeypatch, tune):
     for K, S in ((23, 500), (29, 2048), (14, 40)):
         eng = _engine(layer, K, target, 'xyz', num_gd_iterations=5)
         eng.optimize(eng.initial_angles(1, S))
-        assert eng.last_variant().split(' ')[0] == 'layered/jit(hipcc)', eng.last_variant()
+        assert eng.last_variant().split(' ')[0] == ('zyzl/jit(hipcc)' if S > 256 else 'layered/jit(hipcc)'), eng.last_variant()   # 40 samples: four waves per sample
     assert _ffi.lib().cpf_jit_compiles() == before
     # a shape nobody shipped fails loudly instead of compiling
     eng = _engine([[3, 1], [0, 2], [2, 3], [1, 0]], 9, target, 'yx', num_gd_iterations=2)

@@ -401,9 +401,9 @@ T3_MORE = [
     # samples (5.0 %), the kernel 88 of 1000 (8.8 %), the stored run 39 (3.9 %; 6 of the first 160).  So against the stored
     # numbers only the order of magnitude is asserted here; the kernel-vs-oracle statistics of this very problem are in
     # tests/test_gpu_baseline_configs.py::test_stored_5q_trial_unbiased_against_float32_oracle
-    ('raw_4gt13_xyz_t99', 'layered/jit(hipcc)', 70, 0, None, 4.0),
+    ('raw_4gt13_xyz_t99', 'zyzl/jit(hipcc)', 70, 0, None, 4.0),               # one wave per sample: the ZYZ form of the gate-by-gate layout
     # G4, 5 qubits all-to-all 'xz', 57 blocks, 2000 samples, ONE stored pass
-    ('raw_4gt10_xz_t30', 'layered/jit(hipcc)', 12, 0, None, None),
+    ('raw_4gt10_xz_t30', 'zyzl/jit(hipcc)', 12, 0, None, None),
 ]
 
 

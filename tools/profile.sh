@@ -3,7 +3,8 @@
 #
 #   tools/profile.sh <tag> <cfg> [steps] [T_pmc] [S_pmc]      e.g.  tools/profile.sh r02 cfg2
 #
-#   gpurun_out/<tag>_<cfg>_bench.json          python3 bench.py --config <cfg> (the driver's command, un-profiled)
+#   gpurun_out/<tag>_<cfg>_bench.json          python3 bench.py --config <cfg> --no-other-configs (the driver's command without the
+#                                              extra.other_configs launches, which would enter the kernel statistics; un-profiled)
 #   gpurun_out/<tag>_<cfg>_kernel_trace.csv    rocprofv3 --kernel-trace --stats of the same command: per-dispatch rows
 #   gpurun_out/<tag>_<cfg>_kernel_stats.csv    rocprofv3's own --stats summary (all launches, warm-up included)
 #   gpurun_out/<tag>_<cfg>_pmc/                separate --pmc passes (counters only, no trace domains) over one launch
@@ -16,10 +17,10 @@
 tag=${1:?tag}; cfg=${2:-cfg2}; steps=${3:-20}; tpmc=${4:-}; spmc=${5:-}      # spmc: sample count of the counter passes (default: the configuration's)
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out
 mkdir -p $out
-python3 $root/bench.py --config $cfg --steps $steps > $out/${tag}_${cfg}_bench.json 2> $out/${tag}_${cfg}_bench.err || exit 1
+python3 $root/bench.py --config $cfg --steps $steps --no-other-configs > $out/${tag}_${cfg}_bench.json 2> $out/${tag}_${cfg}_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_${tag}_$cfg
-(cd $root && rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_$cfg -o p --output-format csv -- python3 bench.py --config $cfg --steps $steps --no-cpu-baseline \
+(cd $root && rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_$cfg -o p --output-format csv -- python3 bench.py --config $cfg --steps $steps --no-cpu-baseline --no-other-configs \
    > $out/${tag}_${cfg}_bench_under_rocprof.json 2> $out/${tag}_${cfg}_rocprof.err) || exit 1
 cp $(find /tmp/prof_${tag}_$cfg -name '*kernel_trace.csv' | head -1) $out/${tag}_${cfg}_kernel_trace.csv
 cp $(find /tmp/prof_${tag}_$cfg -name '*kernel_stats.csv' | head -1) $out/${tag}_${cfg}_kernel_stats.csv

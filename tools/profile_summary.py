@@ -26,8 +26,10 @@ if '--pmc-only' not in sys.argv:
     rows = [r for r in csv.DictReader(open(os.path.join(out, f'{tag}_{cfg}_kernel_trace.csv'))) if is_opt(r['Kernel_Name'])]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
-    timed = dur[warm:warm + steps]          # bench.py: warm-up launches, the timed launches, one more launch for the summary
     name = rows[warm]['Kernel_Name'].split('(')[0] if rows else ''
+    rows = [r for r in rows if r['Kernel_Name'].split('(')[0] == name]          # the headline kernel only (no other configuration's launches)
+    dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
+    timed = dur[warm:warm + steps]          # bench.py: warm-up launches, the timed launches, one more launch for the summary
     os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
     with open(os.path.join(root, 'profiles', f'{tag}_{cfg}_kernel_stats.csv'), 'w', newline='') as f:
         w = csv.writer(f)
