@@ -802,6 +802,10 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
         case 6: lw = 2; break;
         default: lw = 0;
     }
+    // round 4: where the one-wave ZYZ-form kernel serves the shape (cpf_zyzl.h) one wave per sample wins from one sample per CU on
+    // (same box, 4-qubit star, 23 blocks: 300 / 500 samples 20.3 ms against 24.5 / 25.1 on four waves; 200 samples 20.0 against 16.4;
+    // 5-qubit chain, 36 blocks: 300 / 500 samples 65.4 against 73.0 / 74.3; 200 samples 65.0 against 42.6)
+    if ((plan->NQ == 4 || plan->NQ == 5) && S > plan->num_cu && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 0)) lw = 0;
     { const TuneVal e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
     if (plan->NQ == 6) lw = 2;
     return lw;

@@ -169,10 +169,12 @@ def test_full_size_properties(cfg):
     lbest = np.take_along_axis(out['loss'], bi[:, None], 1)[:, 0]
     assert (out['passed'] == (lbest <= np.float32(1e-3))).all()
     # re-evaluating the stored best angles reproduces the stored best regloss (another kernel: the generic one applies every
-    # rotation as cos / sin products, the optimiser's register-qubit rotations are three shears - cpf_device.h rot_apply, SH;
-    # 168 gates of float32 rounding apart: 1.3e-6 at most over config 4's 2048 samples)
+    # rotation as cos / sin products; config 2's optimiser merges diagonal runs, config 4's runs the ZYZ form of the blocks -
+    # other factorisations of the same 168 gates in float32: 1.3e-6 / 5.2e-6 at most over the 1024 / 2048 samples, signs mixed.
+    # With the hardware's un-centred 1 / sqrt alone the ZYZ form sat 3-6e-6 ABOVE on every sample: cpf_zyz_math.h zrsqrt)
     re = _np(eng.loss_and_grad(out['params'][:, 1], with_grad=False))
-    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < 3e-6
+    d = re['regloss'] - out['regloss'][:, 1]
+    assert np.abs(d).max() < (3e-6 if cfg == 'cfg2' else 8e-6) and abs(np.median(d)) < 1e-6, (np.abs(d).max(), np.median(d))
     # CZ count recomputed on the host from the best angles
     cp = out['params'][np.arange(S), bi][:, eng.cp_mask == 1] % np.float32(2 * np.pi)
     v = np.full(cp.shape, 2)
@@ -394,7 +396,7 @@ T3_MORE = [
     # Its stored reg values come from older penalty constants, which moves a few CZ counts, not the pass set
     ('raw_toff3_conn_t99', 'split/jit(hipcc) waves=2 states K lone', 3, 195, 14, 0.15),      # 10 blocks: a shipped K-specialised kernel
     # G2 trial 49, 4-qubit star, 500 samples, 7 stored passes (the oracle finds the same 7)
-    ('raw_toff4_star_t49', 'layered/jit(hipcc)', 4, 5, 4, 1.6),
+    ('raw_toff4_star_t49', 'zyzl/jit(hipcc)', 4, 5, 4, 1.6),                 # 500 samples: one wave per sample, the ZYZ form
     # G5, 5-qubit chain 'xyz', 86 blocks, 1000 samples, 39 stored passes.  The stored run used OLDER penalty constants (its
     # stored reg values are 1.4-1.7 x what penalty.py:44-71 gives at the same angles; SURVEY App. D: "don't pin reg"), and a
     # heavier penalty leaves fewer runs below entry_loss: the float32 oracle with today's penalty passes 8 of the first 160
