@@ -924,3 +924,32 @@ def test_zyzl_grouped_launches_are_bit_identical(tune):
     for o in outs[1:]:
         for k in ('params', 'regloss', 'loss', 'reg', 'cz'):
             assert (o[k] == outs[0][k]).all(), k
+
+
+@pytest.mark.parametrize('loss,kind', [('state', 1), ('relative_phase', 2)])
+@pytest.mark.parametrize('layer,K,family', [([[0, 1], [1, 2], [2, 3]], 7, 'zyzl'), ([[0, 1], [1, 2], [2, 3], [3, 4]], 6, 'zyzl'),
+                                            ([[i, (i + 1) % 6] for i in range(6)], 8, 'zyz')])
+def test_other_loss_kinds_on_the_zyz_form_kernels(loss, kind, layer, K, family, tune):
+    """State-preparation and relative-phase losses (tutorial cells 79 / 87) on the ZYZ-form kernels: the relative-phase loss has
+    a non-linear cotangent and drops the final diagonal (moduli only), the state-preparation target has one non-zero column.
+    Short runs with history against the float64 oracle; also zero and one iteration (evaluate only / no update)."""
+    n = max(max(p) for p in layer) + 1
+    N = 2 ** n
+    target = _rand_unitary(n, 9)
+    if loss == 'state':
+        target = np.concatenate([target[:, :1], np.zeros((N, N - 1))], axis=1)
+    tune.set('CPF_LW', '0')
+    rng = np.random.default_rng(4)
+    for T in (15, 1, 0):
+        orc = Oracle(layer, K, target, 'xyz', num_gd_iterations=T, loss_kind=kind, r=0.002)
+        eng = _engine(layer, K, target, 'xyz', num_gd_iterations=T, loss=loss, r=0.002)
+        theta = rng.uniform(0, 2 * np.pi, size=(6, orc.P)).astype(np.float32)
+        out = {k: (v.cpu().numpy() if v is not None else None) for k, v in eng.optimize(theta, keep_history=T > 0).items()}
+        assert eng.last_variant().startswith(family + '/'), eng.last_variant()
+        run = orc.run(theta, np.float64, keep_history=T > 0)
+        if T > 0:
+            assert np.abs(out['history_regloss'] - run['history_loss'])[:, :10].max() < 1e-5
+        assert np.abs(out['regloss'] - run['regloss']).max() < 5e-5
+        assert (out['params'][:, 0] == theta).all() and (out['cz'] == run['cz']).all()
+        if T <= 1:
+            assert (out['params'][:, 1] == theta).all() and (out['regloss'][:, 0] == out['regloss'][:, 1]).all()
