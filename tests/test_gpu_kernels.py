@@ -856,6 +856,7 @@ ZYZL_CASES = [
     ([[1, 0], [0, 1], [2, 3]], 7, 'zyx', 'cp', 'jit'),                       # both qubits of a block on lanes (unrelabelled: 0, 1)
     ([[0, 1], [1, 2], [2, 3], [3, 4]], 36, 'xyz', 'cp', 'jit'),              # 77 items: two per lane
     ([[0, 1], [3, 2]], 1, 'xyz', 'cp', 'jit'),                               # a single block, untouched qubits
+    ([[0, 1], [1, 2]], 12, 'xyz', 'cp', 'jit'),                              # 3 qubits on request (every qubit on lanes; the A/B of DESIGN.md section 4)
 ]
 
 
