@@ -39,11 +39,11 @@ namespace {
 template <int NQ, int ROT, int NSLOT, int... UD>
 hipError_t run_l(const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_zyzl<NQ, ROT, NSLOT, UD...>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_zyzl<NQ, 0, ROT, NSLOT, UD...>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((cpf::k_cp_zyzl<NQ, ROT, NSLOT, UD...>), dim3(grid), dim3(block), lds, stream, za);
+    hipLaunchKernelGGL((cpf::k_cp_zyzl<NQ, 0, ROT, NSLOT, UD...>), dim3(grid), dim3(block), lds, stream, za);
     return hipGetLastError();
 }
 const std::vector<int> CHAIN4_RELABELLED = {0, 2, 2, 3, 3, 1};

@@ -25,18 +25,19 @@ constexpr int ZYZL_TAB_FLOATS = 20;
 struct ZyzlArgs { KArgs k; const ZyzSideInfo* sides; int K, n_rot; };
 
 struct ZyzlLds {                                     // float offsets, per sample; [0, 28) = penalty table
-    int side, stat, btab, surfm, lfin, fw, sums, gsurf, total;
+    int side, stat, btab, surfm, lfin, fw, red, sums, gsurf, total;
     __host__ __device__ static constexpr int up4(int x) { return (x + 3) & ~3; }
-    __host__ __device__ ZyzlLds(int K, int nq) {
+    __host__ __device__ ZyzlLds(int K, int nq, int wps = 1) {
         side = PEN_FLOATS;                     // 2 K x {t, sc, l0, l1, f, -}: the side records
         stat = side + 16 * K;                  // (2 K + nq) x {prev, qubit, -, -, later masks}: static structure (cpf_zyz.h ZyzSideInfo)
         btab = stat + 12 * (2 * K + nq);       // K per-block tables
         surfm = btab + ZYZL_TAB_FLOATS * K;    // nq x 2x2 complex
         lfin = surfm + 8 * nq;                 // nq x (l0, l1)
         fw = up4(lfin + 4 * nq);               // 4 x 64 flip bits
-        sums = fw + 8;                         // [K][32]: generator sums, reduce8_rows slabs
-        gsurf = sums + K * 32;
-        total = up4(gsurf + ((3 * nq + 7) / 8) * 32);
+        red = fw + 8;                          // [wps][3]: loss / penalty partial sums of the waves
+        sums = red + 16;                       // [wps][K][32]: generator sums, reduce8_rows slabs
+        gsurf = sums + wps * K * 32;           // [wps][NBATCH][32]
+        total = up4(gsurf + wps * ((3 * nq + 7) / 8) * 32);
     }
 };
 
@@ -239,9 +240,12 @@ __device__ __forceinline__ void zl_product(f2 (&x)[L::E], f2 base, const F& fac)
 // block's CP angle), a qubit's three surface angles: Adam state, (cos, sin), the side's factors and the gradients the chain phase
 // produces all stay in the owner's registers; only what other lanes need crosses LDS (the side records, the per-block tables, the
 // surface matrices, the reduced sums).
-template <int NQ, int ROT, int NSLOT, int... UD>
+// LW: log2 of the waves per sample - 0 (one wave; up to four samples per workgroup) or 2 (four waves: the columns are split over
+// the waves, for launches with at most one sample per CU; the items spread over all 256 lanes).
+template <int NQ, int LW, int ROT, int NSLOT, int... UD>
 __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
-    using L = Lay<NQ, 0>;
+    using L = Lay<NQ, LW>;
+    constexpr int WPS = L::WPS, THREADS = L::THREADS;
     using PL = PairList<UD...>;
     constexpr int LL = sizeof...(UD) / 2;
     static_assert(LL > 0 && ROT != 0, "the ZYZ-form kernel is specialised on the layer and the rotation string");
@@ -251,18 +255,22 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     const KArgs& a = za.k;
     extern __shared__ __attribute__((aligned(16))) float smem_wg[];
     const int P = a.P, K = za.K;
-    const ZyzlLds lds(K, NQ);
-    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int tid = (int)threadIdx.x & 63, lane = tid;
-    const int64_t s_idx = (int64_t)blockIdx.x * (a.group > 1 ? a.group : 1) + sub;
-    if (s_idx >= a.nsamples) return;
+    const ZyzlLds lds(K, NQ, WPS);
+    const int sub = WPS == 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+    const int tid = WPS == 1 ? ((int)threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63;
+    const int wave = WPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t s_idx = (int64_t)blockIdx.x * (a.group > 1 && WPS == 1 ? a.group : 1) + sub;
+    if (WPS == 1 && s_idx >= a.nsamples) return;
     float* smem = smem_wg + sub * lds.total;
+    float* red = smem + lds.red;
+    float* sums_w = smem + lds.sums + wave * K * 32;
+    float* gsurf_w = smem + lds.gsurf + wave * NBATCH * 32;
     float4* sidev = reinterpret_cast<float4*>(smem + lds.side);
     unsigned long long* fw = reinterpret_cast<unsigned long long*>(smem + lds.fw);
     const float* init = a.init + s_idx * P;
     const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
     float* out_best = a.out_params + (s_idx * 2 + 1) * P;
-    const int col = L::col_index(lane, 0);
+    const int col = L::col_index(lane, wave);
     const int dst_lane = reduce8_dst_lane(lane);
     const int nw = (2 * K + 63) >> 6, NI = 2 * K + NQ;
     ZlLane<L> ln;
@@ -290,7 +298,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
         Item& t = itm[s];
-        const int i = tid + 64 * s;
+        const int i = tid + THREADS * s;
         t.kind = i < 2 * K ? 0 : (i < NI ? 1 : 2);
         t.prev = -1; t.cacb = 0; t.d0 = 1.f; t.psl = 0.f; t.pval = 0.f; t.m = 0;
         t.sd = zyz::Side{};
@@ -325,7 +333,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
             for (int k = 0; k < 4; k++) { st[4 + 2 * k] = (int)(si.later[k] & 0xffffffffull); st[5 + 2 * k] = (int)(si.later[k] >> 32); }
         }
     }
-    lds_sync<1>();
+    lds_sync<WPS>();
     auto load_side = [&](int w) {
         const float4 s0 = sidev[2 * w], s1 = sidev[2 * w + 1];
         zyz::Side sd;
@@ -338,9 +346,14 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         for (int k = 0; k < nw; k++) n += __popcll(fw[k] & mask[k]);
         return n & 1;
     };
-    auto slab_sum = [&](int base, int idx, int v) {
-        const float4 q = *reinterpret_cast<const float4*>(smem + base + 32 * idx + 4 * v);
-        return (q.x + q.y) + (q.z + q.w);
+    auto slab_sum = [&](int base, int stride_w, int idx, int v) {          // over the waves' slabs and their four row partials
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WPS; wv++) {
+            const float4 q = *reinterpret_cast<const float4*>(smem + base + wv * stride_w + 32 * idx + 4 * v);
+            sum += (q.x + q.y) + (q.z + q.w);
+        }
+        return sum;
     };
 
     f2 psi[E], cot[E];
@@ -375,7 +388,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                         t.pval = penalty_lds(smem, a.pen_kind, t.th[3], sl);
                         t.psl = a.r * sl;
                     }
-                    const int side = (tid + 64 * s) & 1;
+                    const int side = (tid + THREADS * s) & 1;
                     auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
                         const int k = (idx - 1) >> 1;
                         c = t.cs[k][0]; sn = t.cs[k][1]; kind = 0;
@@ -383,21 +396,21 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                     const int m_keep = t.sd.m;
                     t.sd = zyz::side_build<ROT>(rrec, NR, side);
                     t.sd.m = m_keep;
-                    const int w = tid + 64 * s;
+                    const int w = tid + THREADS * s;
                     sidev[2 * w] = make_float4(t.sd.t, t.sd.sc, t.sd.l0.re, t.sd.l0.im);
                     sidev[2 * w + 1] = make_float4(t.sd.l1.re, t.sd.l1.im, __int_as_float(t.sd.f), 0.f);
                     flip = t.sd.f != 0;
                 }
             }
             const unsigned long long bits = __builtin_amdgcn_ballot_w64(flip);
-            if (lane == 0) fw[s] = bits;
+            if (lane == 0) fw[s * WPS + wave] = bits;
         }
-        lds_sync<1>();
+        lds_sync<WPS>();
         // ================= build B: pending-flip parities; side 0: the block's table; qubit: surface matrix, final left factor
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) {
             Item& t = itm[s];
-            const int i = tid + 64 * s;
+            const int i = tid + THREADS * s;
             if (t.kind == 0) {
                 t.sd.m = parity_of(i);
                 if ((i & 1) == 0) {
@@ -427,7 +440,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 *reinterpret_cast<float4*>(smem + lds.lfin + 4 * q) = lf;
             }
         }
-        lds_sync<1>();
+        lds_sync<WPS>();
 
         // ================= forward: the (flipped) product state of the surface gates, then the blocks
         {
@@ -499,6 +512,13 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+        if constexpr (WPS > 1) {                 // fixed order: deterministic
+            lds_sync<WPS>();
+            if (lane == 0) { red[wave * 3] = acc[0]; red[wave * 3 + 1] = acc[1]; red[wave * 3 + 2] = acc[2]; }
+            lds_sync<WPS>();
+#pragma unroll
+            for (int k = 0; k < 3; k++) { float sum = 0.f; for (int w = 0; w < WPS; w++) sum += red[w * 3 + k]; acc[k] = sum; }
+        }
         const float tr = acc[0], ti = acc[1];
         const float ab = sqrtf(fmaf(tr, tr, ti * ti));
         const float loss = (a.loss_kind == 2) ? 1.f - tr * a.inv_dim2 : 1.f - ab * ab * a.inv_dim2;
@@ -553,7 +573,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 zl_use(t, cur, ln);
                 float d8[8];
                 zl_bwd<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, cot, t, ln, d8);
-                reduce8_rows<true>(d8, smem + lds.sums + 32 * b, lane, dst_lane);
+                reduce8_rows<true>(d8, sums_w + 32 * b, lane, dst_lane);
                 gate_fence<L>();
                 b--;
             };
@@ -595,19 +615,19 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 float d8[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) d8[k] = ds[8 * bt + k];
-                reduce8_rows(d8, smem + lds.gsurf + 32 * bt, lane, dst_lane);
+                reduce8_rows(d8, gsurf_w + 32 * bt, lane, dst_lane);
             }
         }
-        lds_sync<1>();
+        lds_sync<WPS>();
 
         // ================= chain: the gradients of the item's own angles, into the owner's registers
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) {
             Item& t = itm[s];
-            const int i = tid + 64 * s;
+            const int i = tid + THREADS * s;
             if (t.kind == 0) {
                 const int b = i >> 1, side = i & 1, kx = 3 * side;
-                const float px = slab_sum(lds.sums, b, kx), py = slab_sum(lds.sums, b, kx + 1), pz = slab_sum(lds.sums, b, kx + 2);
+                const float px = slab_sum(lds.sums, K * 32, b, kx), py = slab_sum(lds.sums, K * 32, b, kx + 1), pz = slab_sum(lds.sums, K * 32, b, kx + 2);
                 auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
                     const int k = (idx - 1) >> 1;
                     c = t.cs[k][0]; sn = t.cs[k][1]; kind = 0;
@@ -622,22 +642,23 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                     for (int sd2 = 0; sd2 < 2; sd2++) {
                         const int* st = reinterpret_cast<const int*>(smem + lds.stat + 12 * (i + sd2));
                         const int wp = st[0], q = st[1];
-                        pzq[sd2] = wp < 0 ? slab_sum(lds.gsurf, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, wp >> 1, 3 * (wp & 1) + 2);
+                        pzq[sd2] = wp < 0 ? slab_sum(lds.gsurf, NBATCH * 32, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, K * 32, wp >> 1, 3 * (wp & 1) + 2);
                     }
-                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, b, 6), pzq[0], pzq[1], t.cacb, t.d0);
+                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], t.cacb, t.d0);
                 }
             } else if (t.kind == 1) {
                 const int q = i - 2 * K;
                 float pv[3], gs[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) pv[k] = slab_sum(lds.gsurf, (3 * q + k) >> 3, (3 * q + k) & 7);
+                for (int k = 0; k < 3; k++) pv[k] = slab_sum(lds.gsurf, NBATCH * 32, (3 * q + k) >> 3, (3 * q + k) & 7);
                 zyz::chain_surface(gs, pv[0], pv[1], pv[2], t.m, t.cs[1][0], t.cs[1][1], t.cs[2][0], t.cs[2][1]);
 #pragma unroll
                 for (int k = 0; k < 3; k++) t.g[k] = gs[k];
             }
         }
-        // no barrier: the next step's owner phase reads only this lane's registers; its LDS writes (side records, flip words) touch
-        // what this phase did not read after ... the sums slabs are rewritten only by the next backward sweep
+        // one wave: no barrier - the next step's owner phase reads only this lane's registers.  Several waves: another wave may still be
+        // reading the side records / static structure this wave's owner phase is about to overwrite
+        if constexpr (WPS > 1) lds_sync<WPS>();
     }
 
     // ---- epilogue: reg recompute, loss = regloss - reg (optimization.py:365-370); argmin, CZ count, entry-loss flag.  Every CP
@@ -656,6 +677,13 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+    if constexpr (WPS > 1) {
+        lds_sync<WPS>();
+        if (lane == 0) { red[wave * 3] = acc[0]; red[wave * 3 + 1] = acc[1]; red[wave * 3 + 2] = acc[2]; }
+        lds_sync<WPS>();
+#pragma unroll
+        for (int k = 0; k < 3; k++) { float sum = 0.f; for (int w = 0; w < WPS; w++) sum += red[w * 3 + k]; acc[k] = sum; }
+    }
     if (tid == 0) {
         const float reg0 = a.use_reg ? a.r * acc[0] : 0.f, reg1 = a.use_reg ? a.r * acc[1] : 0.f;
         const float l0 = first - reg0, l1 = best - reg1;
@@ -667,9 +695,9 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     }
 }
 
-template <int NQ, int ROT, int NSLOT, int... UD>
+template <int NQ, int LW, int ROT, int NSLOT, int... UD>
 __global__ __launch_bounds__(256, 1) void k_cp_zyzl(const ZyzlArgs za) {
-    zyzl_body<NQ, ROT, NSLOT, UD...>(za);
+    zyzl_body<NQ, LW, ROT, NSLOT, UD...>(za);
 }
 
 }  // namespace cpf

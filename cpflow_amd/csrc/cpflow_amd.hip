@@ -591,47 +591,51 @@ bool try_zyz(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream,
 
 // ---- ZYZ form on the gate-by-gate layout (cpf_zyzl.h): one wave per sample, 4 and 5 qubits, CP or CZ blocks,
 // layer-specialised (ahead of time for config 4's relabelled chain, at run time otherwise).  CPF_ZYZL=0|1 switches it.
-int zyzl_slots(const cpf_plan* plan) { return (2 * plan->K + plan->n + 63) / 64; }          // items (sides + qubits) per lane
-cpf_jit::Spec zyzl_jit_spec(int nq, int rot, int nslot, const std::vector<int>& ud) {
-    cpf_jit::Spec spec{"cpf_zyzl.h", cpf_jit::body_expr("zyzl_body", {nq, rot, nslot}, ud), 256};      // up to four one-wave samples per workgroup
+int zyzl_slots(const cpf_plan* plan, int lw) { const int th = 64 << lw; return (2 * plan->K + plan->n + th - 1) / th; }      // items (sides + qubits) per lane
+cpf_jit::Spec zyzl_jit_spec(int nq, int lw, int rot, int nslot, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyzl.h", cpf_jit::body_expr("zyzl_body", {nq, lw, rot, nslot}, ud), 256};      // up to four one-wave samples per workgroup
     spec.arg = "cpf::ZyzlArgs";
     spec.min_waves = 1;
     spec.flags = {CPF_DENSE_MLLVM_FLAGS};
     return spec;
 }
 bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
-    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw != 0 || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
-    if (plan->K < 1 || zyzl_slots(plan) > 4 || plan->n_rot < 1 || plan->n_rot > 3 || plan->entangler == CPF_ENTANGLER_CX) return false;
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || (lw != 0 && lw != 2) || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
+    if (lw == 2 && plan->NQ == 3) return false;          // four waves per sample: 4 and 5 qubits (the columns split over the waves)
+    if (plan->K < 1 || zyzl_slots(plan, lw) > 4 || plan->n_rot < 1 || plan->n_rot > 3 || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     const TuneVal e = tuning("CPF_ZYZL");
-    return e ? e[0] != '0' : plan->NQ >= 4;          // 3 qubits (one amplitude per lane): on request (A/B against the two-ended kernel)
+    // default: one wave per sample on 4 and 5 qubits; four waves per sample on 5 qubits (same box, 100 / 256 samples: chain 36 blocks
+    // 33.4 / 33.5 ms against 42.3 / 42.7 on the gate-by-gate kernel, 86 blocks 67.6 / 68.1 against 93.8 / 94.5; the 4-qubit star,
+    // every row qubit on lanes, 17.4 against 16.2: stays).  3 qubits: on request (the A/B of DESIGN.md section 4)
+    return e ? e[0] != '0' : (lw == 0 ? plan->NQ >= 4 : plan->NQ == 5);
 }
 bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
     const int nq = plan->NQ, rot = dense_rot_code(plan), which = labelling_for(plan, a_in.mode, lw);
-    const int nslot = zyzl_slots(plan);
-    const bool have_aot = cpf_zyzl_has_aot(nq, rot, nslot, plan->layer_ud);
+    const int nslot = zyzl_slots(plan, lw);
+    const bool have_aot = lw == 0 && cpf_zyzl_has_aot(nq, rot, nslot, plan->layer_ud);
     const cpf_jit::Kernel* jk = nullptr;
     if (!have_aot) {
         if (!plan->use_jit) return false;
-        jk = &cpf_jit::get(plan->device, zyzl_jit_spec(nq, rot, nslot, plan->layer_ud));
+        jk = &cpf_jit::get(plan->device, zyzl_jit_spec(nq, lw, rot, nslot, plan->layer_ud));
         if (!jk->fn) {
             plan->jit_note = jk->error;
             if (jk->error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", jk->error.c_str()); return true; }
             return false;
         }
     }
-    const size_t lds1 = (size_t)cpf::ZyzlLds(plan->K, nq).total * sizeof(float);
+    const size_t lds1 = (size_t)cpf::ZyzlLds(plan->K, nq, 1 << lw).total * sizeof(float);
     if (lds1 > (size_t)plan->lds_per_cu) return false;
     cpf::KArgs a = a_in;
-    a.group = layered_group(plan, lw, S, lds1);
+    a.group = lw == 0 ? layered_group(plan, lw, S, lds1) : 1;
     if (nq == 3 && S > plan->num_cu) a.group = 4;          // four waves of a workgroup land on the CU's four SIMDs (cpf_layered.h)
     const size_t lds = lds1 * a.group;
     if ((*rc = zyz_sides(plan, which))) return true;
     const cpf::ZyzlArgs za{a, plan->zyz_sides[which].as<cpf::ZyzSideInfo>(), plan->K, plan->n_rot};
-    const unsigned grid = (unsigned)((S + a.group - 1) / a.group), block = 64u * a.group;
+    const unsigned grid = (unsigned)((S + a.group - 1) / a.group), block = lw == 0 ? 64u * a.group : 64u << lw;
     hipError_t e = hipSuccess;
-    const std::string tail = std::string(" waves=1") + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
+    const std::string tail = std::string(" waves=") + (lw ? "4" : "1") + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
     if (have_aot) {
         cpf_zyzl_launch_aot(nq, rot, nslot, plan->layer_ud, za, grid, block, lds, stream, &e);
         plan->variant = "zyzl/aot" + tail;
@@ -1194,12 +1198,12 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     }
     const int lw = choose_lw(&pl, num_samples);
     select_labelling(&pl, labelling_for(&pl, cpf::MODE_OPTIMIZE, lw));
-    if (zyzl_wanted(&pl, cpf::MODE_OPTIMIZE, lw) && !cpf_zyzl_has_aot(pl.NQ, dense_rot_code(&pl), zyzl_slots(&pl), pl.layer_ud)) {
-        const cpf_jit::Spec spec = zyzl_jit_spec(pl.NQ, dense_rot_code(&pl), zyzl_slots(&pl), pl.layer_ud);
+    if (zyzl_wanted(&pl, cpf::MODE_OPTIMIZE, lw) && !(lw == 0 && cpf_zyzl_has_aot(pl.NQ, dense_rot_code(&pl), zyzl_slots(&pl, lw), pl.layer_ud))) {
+        const cpf_jit::Spec spec = zyzl_jit_spec(pl.NQ, lw, dense_rot_code(&pl), zyzl_slots(&pl, lw), pl.layer_ud);
         const cpf_jit::Code code = cpf_jit::build(spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
         if (int rc = precompile_landed(code, spec.body)) return rc;
-        report += "zyzl/jit(" + code.backend + ") waves=1" + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+        report += "zyzl/jit(" + code.backend + ") waves=" + (lw ? "4" : "1") + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
         built++;
     }
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {

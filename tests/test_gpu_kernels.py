@@ -277,7 +277,7 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
     ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'split/jit(hipcc) waves=2 states K'),       # the local-minimum study's shape: shipped K-specialised
     ('cz', [[0, 1], [0, 2], [1, 2]], 15, 'xyz', 3000, 'layered/jit'),                            # a block count nobody shipped, SIMDs full: one wave per sample
     ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'layered/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'split/jit'),
-    ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'layered/jit'),
+    ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'zyzl/jit'),
     ('cx', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'layered/jit'), ('cx', [[2, 1], [0, 2]], 7, 'zy', 1500, 'layered/jit'),
     ('cx', [[3, 0], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cx', [[0, 1], [1, 2], [2, 3], [3, 4]], 9, 'xz', 2000, 'layered/jit')])
 def test_cz_cx_blocks_run_on_the_specialised_kernels(ent, layer, K, rot, S, kind):
@@ -954,3 +954,35 @@ def test_other_loss_kinds_on_the_zyz_form_kernels(loss, kind, layer, K, family, 
         assert (out['params'][:, 0] == theta).all() and (out['cz'] == run['cz']).all()
         if T <= 1:
             assert (out['params'][:, 1] == theta).all() and (out['regloss'][:, 0] == out['regloss'][:, 1]).all()
+
+
+@pytest.mark.parametrize('layer,K,rot,ent', [([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp'), ([[0, 1], [0, 2], [0, 3]], 23, 'xyz', 'cp'),
+                                             ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xz', 'cp'), ([[4, 0], [1, 3], [2, 4], [3, 0]], 9, 'y', 'cz'),
+                                             ([[i, j] for i in range(5) for j in range(i + 1, 5)], 57, 'xyz', 'cp')])
+def test_zyz_form_with_four_waves_per_sample_matches_oracle(layer, K, rot, ent, tune):
+    """The four-waves-per-sample instance of cpf_zyzl.h (columns split over the waves, every row qubit of a 4-qubit problem on
+    lanes, items spread over 256 lanes, sums and loss partials crossing LDS between the waves): short Adam run with history
+    against the float64 oracle, frozen mask, and bit-identical outputs from two launches."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 5)
+    T, S = 12, 5
+    tune.set('CPF_LW', '2')
+    tune.set('CPF_ZYZL', '1')
+    kw = dict(entangler=ent, num_gd_iterations=T, r=0.003)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(3, S)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant() == 'zyzl/jit(hipcc) waves=4', eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6
+    assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 2e-5
+    assert np.abs(out['history_params'] - ref['history_params']).max() < (2e-4 if K < 40 else 4e-4)      # 414 angles, 12 steps: 2.04e-4
+    assert (out['cz'] == ref['cz']).all() and np.abs(out['reg'] - ref['reg']).max() < 1e-6
+    again = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    for k in out:
+        assert np.array_equal(out[k], again[k]), k
+    frozen = np.zeros((S, orc.P), dtype=np.uint8)
+    frozen[1::2, ::5] = 1
+    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
+    assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
