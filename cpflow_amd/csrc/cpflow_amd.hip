@@ -600,15 +600,15 @@ cpf_jit::Spec zyzl_jit_spec(int nq, int lw, int rot, int nslot, const std::vecto
     return spec;
 }
 bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
-    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || (lw != 0 && lw != 2) || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
-    if (lw == 2 && plan->NQ == 3) return false;          // four waves per sample: 4 and 5 qubits (the columns split over the waves)
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw < 0 || lw > 2 || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
+    if (lw > 0 && plan->NQ == 3) return false;          // two / four waves per sample: 4 and 5 qubits (the columns split over the waves)
     if (plan->K < 1 || zyzl_slots(plan, lw) > 4 || plan->n_rot < 1 || plan->n_rot > 3 || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     const TuneVal e = tuning("CPF_ZYZL");
     // default: one wave per sample on 4 and 5 qubits; four waves per sample on 5 qubits (same box, 100 / 256 samples: chain 36 blocks
     // 33.4 / 33.5 ms against 42.3 / 42.7 on the gate-by-gate kernel, 86 blocks 67.6 / 68.1 against 93.8 / 94.5; the 4-qubit star,
     // every row qubit on lanes, 17.4 against 16.2: stays).  3 qubits: on request (the A/B of DESIGN.md section 4)
-    return e ? e[0] != '0' : (lw == 0 ? plan->NQ >= 4 : plan->NQ == 5);
+    return e ? e[0] != '0' : (lw == 0 ? plan->NQ >= 4 : (lw == 2 && plan->NQ == 5));
 }
 bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
@@ -635,7 +635,7 @@ bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStre
     const cpf::ZyzlArgs za{a, plan->zyz_sides[which].as<cpf::ZyzSideInfo>(), plan->K, plan->n_rot};
     const unsigned grid = (unsigned)((S + a.group - 1) / a.group), block = lw == 0 ? 64u * a.group : 64u << lw;
     hipError_t e = hipSuccess;
-    const std::string tail = std::string(" waves=") + (lw ? "4" : "1") + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
+    const std::string tail = " waves=" + std::to_string(1 << lw) + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
     if (have_aot) {
         cpf_zyzl_launch_aot(nq, rot, nslot, plan->layer_ud, za, grid, block, lds, stream, &e);
         plan->variant = "zyzl/aot" + tail;
@@ -810,7 +810,7 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
     // (same box, 4-qubit star, 23 blocks: 300 / 500 samples 20.3 ms against 24.5 / 25.1 on four waves; 200 samples 20.0 against 16.4;
     // 5-qubit chain, 36 blocks: 300 / 500 samples 65.4 against 73.0 / 74.3; 200 samples 65.0 against 42.6)
     if ((plan->NQ == 4 || plan->NQ == 5) && S > plan->num_cu && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 0)) lw = 0;
-    { const TuneVal e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : 2; }
+    { const TuneVal e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : ((e[0] == '1' && plan->NQ < 6 && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 1)) ? 1 : 2); }
     if (plan->NQ == 6) lw = 2;
     return lw;
 }
@@ -1203,7 +1203,7 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
         const cpf_jit::Code code = cpf_jit::build(spec);
         if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
         if (int rc = precompile_landed(code, spec.body)) return rc;
-        report += "zyzl/jit(" + code.backend + ") waves=" + (lw ? "4" : "1") + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+        report += "zyzl/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
         built++;
     }
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {

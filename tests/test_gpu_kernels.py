@@ -811,6 +811,7 @@ def test_zyz_form_kernel_matches_oracle(layer, K, rot, ent, lw, how, tune):
     outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
     assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
     tune.set('CPF_DENSE', '0')                  # the gate-by-gate kernels on the same inputs
+    tune.set('CPF_ZYZL', '0')
     eng0 = _engine(layer, K, target, rot, **kw)
     out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
     assert not eng0.last_variant().startswith(('dense', 'zyz'))
@@ -905,7 +906,7 @@ def test_zyz_form_on_the_gate_by_gate_layout_matches_oracle(layer, K, rot, ent, 
     tune.set('CPF_ZYZL', '0')                   # the gate-by-gate kernel on the same inputs
     eng0 = _engine(layer, K, target, rot, **kw)
     out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}
-    assert eng0.last_variant().startswith(('layered', 'generic')), eng0.last_variant()      # four rotation letters: the generic kernel
+    assert eng0.last_variant().startswith(('layered', 'generic', 'split')), eng0.last_variant()      # 3 qubits: the two-ended kernel
     assert np.abs(outf['regloss'] - out0['regloss'])[:4].max() < 2e-5
 
 
@@ -978,7 +979,7 @@ def test_zyz_form_with_four_waves_per_sample_matches_oracle(layer, K, rot, ent, 
     assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6
     assert np.abs(out['history_regloss'] - ref['history_loss']).max() < 2e-5
     assert np.abs(out['history_params'] - ref['history_params']).max() < (2e-4 if K < 40 else 4e-4)      # 414 angles, 12 steps: 2.04e-4
-    assert (out['cz'] == ref['cz']).all() and np.abs(out['reg'] - ref['reg']).max() < 1e-6
+    assert (out['cz'] == ref['cz']).all() and np.abs(out['reg'] - ref['reg']).max() < (1e-6 if K < 40 else 2e-6)
     again = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
     for k in out:
         assert np.array_equal(out[k], again[k]), k
