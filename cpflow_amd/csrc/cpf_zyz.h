@@ -77,12 +77,24 @@ __device__ __forceinline__ void zyz_load_tab(const float* gp, ZyzTab& g) {
 // current table here, the caller issues the next block's loads right after it (cpf_dense.h dense_touch_s)
 __device__ __forceinline__ void zyz_touch(const ZyzTab& g) { asm volatile("" :: "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt)); }
 
+#ifndef CPF_ZYZ_FWD2
+#define CPF_ZYZ_FWD2 1           // A/B: 0 = one group of four amplitudes per asm statement in the forward sweep
+#endif
 template <int E, int RA, int RB>
 __device__ __forceinline__ void zyz_apply(f2 (&x)[E], const ZyzTab& g) {
+    // the groups of the block in pairs: two groups per statement, their instructions alternating
+    int prev = -1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         if (e & ((1 << RA) | (1 << RB))) continue;
-        zyz_group_fwd(x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+        if (CPF_ZYZ_FWD2 != 0 && E >= 8) {
+            if (prev < 0) { prev = e; continue; }
+            zyz_group_fwd2(x[prev], x[prev | (1 << RA)], x[prev | (1 << RB)], x[prev | (1 << RA) | (1 << RB)],
+                           x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+            prev = -1;
+        } else {
+            zyz_group_fwd(x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+        }
     }
 }
 // backward pass of one block; d8 receives this thread's shares {Px, Py, Pz of the lo qubit, the same of the hi qubit, S11, -}

@@ -443,7 +443,10 @@ int dense_lw(const cpf_plan* plan, int64_t S) {
     const TuneVal w = tuning("CPF_DENSE_LW");
     const int64_t simds = (int64_t)plan->num_cu * 4;
     switch (plan->NQ) {
-        case 6: return (w && w[0] == '2') ? 2 : 1;
+        // 6 qubits: two waves per sample (32 amplitudes per thread) once the samples fill every SIMD twice, four waves (16 per
+        // thread) below: same box, ZYZ-form kernel, config 5's shape at 64 / 256 / 512 samples 116.9 / 118.2 / 206.3 ms on four waves
+        // against 174.2 / 175.1 / 300.7 on two; 768 samples 300.1 against 301.4; 1024 samples 392.8 against 332.3
+        case 6: return w ? (w[0] == '2' ? 2 : 1) : (2 * S <= simds ? 2 : 1);
         case 5: return (w ? w[0] == '1' : 2 * S < simds) ? 1 : 0;
         default: return 0;
     }

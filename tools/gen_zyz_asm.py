@@ -56,6 +56,25 @@ def forward():
     return lines
 
 
+def forward2():
+    """two groups in one statement, instruction by instruction in turn: every result is read four to eight instructions later.
+    Operands: %0-%3 o (group A), %4-%7 x (A), %8-%11 o (B), %12-%15 x (B), %16-%20 table"""
+    a = forward()
+    ren_a = {f'%{k}': f'%{k}' for k in range(8)}
+    ren_a.update({'%8': '%16', '%9': '%17', '%10': '%18', '%11': '%19', '%12': '%20'})
+    ren_b = {f'%{k}': f'%{k + 8}' for k in range(8)}
+    ren_b.update({'%8': '%16', '%9': '%17', '%10': '%18', '%11': '%19', '%12': '%20'})
+    import re
+
+    def ren(line, m):
+        return re.sub(r'%(\d+)', lambda mo: m['%' + mo.group(1)], line)
+    out = []
+    for line in a:
+        out.append(ren(line, ren_a))
+        out.append(ren(line, ren_b))
+    return out
+
+
 def acc(dst, a, b, swap, neg, first):
     """dst (+)= (+-a) (x) (swap(b) or b)"""
     if first:                 # v_pk_mul_f32: two sources
@@ -128,6 +147,17 @@ __device__ __forceinline__ void zyz_group_fwd(f2& x0, f2& x1, f2& x2, f2& x3, co
         : "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt));
     x0 = o0; x1 = o1; x2 = o2; x3 = o3;
 }
+// two groups at once (the same table): their instructions alternate, so that no packed instruction reads a result younger than four
+// instructions (dependent packed instructions issue at half rate)
+__device__ __forceinline__ void zyz_group_fwd2(f2& x0, f2& x1, f2& x2, f2& x3, f2& y0, f2& y1, f2& y2, f2& y3, const ZyzTab& g) {
+    f2 o0, o1, o2, o3, q0, q1, q2, q3;
+    asm(
+%s
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3),
+          "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3)
+        : "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt));
+    x0 = o0; x1 = o1; x2 = o2; x3 = o3; y0 = q0; y1 = q1; y2 = q2; y3 = q3;
+}
 #define CPF_ZYZ_BWD_OPERANDS(ACC)                                                                                                  \\
         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3),                                          \\
           ACC(a.axlo), ACC(a.aylo), ACC(a.axhi), ACC(a.ayhi), ACC(a.ta), ACC(a.tb), ACC(a.cc),                                    \\
@@ -154,7 +184,7 @@ __device__ __forceinline__ void zyz_group_bwd(f2& p0, f2& p1, f2& p2, f2& p3, f2
 
 
 def render():
-    return HEADER % (c_string(forward()), c_string(backward(True)), c_string(backward(False)))
+    return HEADER % (c_string(forward()), c_string(forward2()), c_string(backward(True)), c_string(backward(False)))
 
 
 if __name__ == '__main__':
