@@ -605,6 +605,7 @@ cpf_jit::Spec zyzl_jit_spec(int nq, int lw, int rot, int nslot, const std::vecto
 bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
     if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || lw < 0 || lw > 2 || plan->n != plan->NQ || plan->NQ < 3 || plan->NQ > 5) return false;
     if (lw > 0 && plan->NQ == 3) return false;          // two / four waves per sample: 4 and 5 qubits (the columns split over the waves)
+    if (2 * plan->K + plan->n > 256) return false;          // side / qubit items: four 64-bit words of flip bits and of "later sides" masks
     if (plan->K < 1 || zyzl_slots(plan, lw) > 4 || plan->n_rot < 1 || plan->n_rot > 3 || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     const TuneVal e = tuning("CPF_ZYZL");
