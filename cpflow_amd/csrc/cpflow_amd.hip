@@ -813,7 +813,10 @@ int choose_lw(const cpf_plan* plan, int64_t S) {
     // round 4: where the one-wave ZYZ-form kernel serves the shape (cpf_zyzl.h) one wave per sample wins from one sample per CU on
     // (same box, 4-qubit star, 23 blocks: 300 / 500 samples 20.3 ms against 24.5 / 25.1 on four waves; 200 samples 20.0 against 16.4;
     // 5-qubit chain, 36 blocks: 300 / 500 samples 65.4 against 73.0 / 74.3; 200 samples 65.0 against 42.6)
-    if ((plan->NQ == 4 || plan->NQ == 5) && S > plan->num_cu && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 0)) lw = 0;
+    if (plan->NQ == 4 && S > plan->num_cu && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 0)) lw = 0;
+    // 5 qubits on the ZYZ form: four waves per sample up to two waves per SIMD's worth of samples (chain, 36 blocks, 512 samples:
+    // 51.4 ms on four waves against 65.8 on one and 71.5 on two; 1000 samples 97.2 against 66.7), one wave above
+    if (plan->NQ == 5 && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 0) && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 2)) lw = 2 * S <= simds ? 2 : 0;
     { const TuneVal e = tuning("CPF_LW"); if (e && plan->NQ > 3) lw = (e[0] == '0') ? 0 : ((e[0] == '1' && plan->NQ < 6 && zyzl_wanted(plan, cpf::MODE_OPTIMIZE, 1)) ? 1 : 2); }
     if (plan->NQ == 6) lw = 2;
     return lw;

@@ -220,8 +220,9 @@ def test_config4_unbiased_against_float32_oracle(kernel, tune):
 
 def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
     """The 5-qubit benchmark problem of paper/results/benchmarks/res_4gt13_91 trial 99 (chain, 'xyz', 86 blocks, 617
-    angles, its stored target, seed and r): 2 x 500 samples over 2000 iterations on the relabelled
-    one-wave ZYZ-form kernel from the shipped cache against the float32 oracle.  The stored run itself used older penalty
+    angles, its stored target, seed and r): 2 x 500 samples over 2000 iterations on the
+    four-wave ZYZ-form kernel from the shipped cache against the float32 oracle (the one-wave form runs the same problem at its
+    stored 1000 samples in tests/test_gpu_synthesis.py::test_T3_more_stored_trials_end_of_run).  The stored run itself used older penalty
     constants, so it pins loss and initial angles only (tests/test_gpu_synthesis.py); this is the full-length pin of the
     5-qubit kernel."""
     monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
@@ -237,7 +238,7 @@ def test_stored_5q_trial_unbiased_against_float32_oracle(monkeypatch):
     pooled = []
     for seed in (Trial.seed, Trial.seed + 1):
         Trial.seed = seed
-        _unbiased_against_float32_oracle(Trial, 500, list(range(40, 80, 4)), 0.0, 3e-3, 3e-3, 'zyzl/jit(hipcc) waves=1', same_flag_min=0.8, pooled=pooled)
+        _unbiased_against_float32_oracle(Trial, 500, list(range(40, 80, 4)), 0.0, 3e-3, 3e-3, 'zyzl/jit(hipcc) waves=4', same_flag_min=0.8, pooled=pooled)      # 500 samples: four waves per sample
     kp, op, n = sum(p[0] for p in pooled), sum(p[1] for p in pooled), sum(p[2] for p in pooled)
     rate = (kp + op) / (2 * n)
     sigma = np.sqrt(2 * n * rate * (1 - rate))
