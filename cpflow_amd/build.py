@@ -104,7 +104,8 @@ def precompile(shapes=None, workers=None, verbose=True):
     os.makedirs(JIT_DIR, exist_ok=True)
     os.chmod(JIT_DIR, 0o700)
     # code objects are keyed by a hash of the kernel headers: after a header edit every shipped object is stale
-    stamp, tag = os.path.join(JIT_DIR, '.stamp'), str(max(os.path.getmtime(d) for d in DEPS if d.endswith('.h')))
+    # (the kernel headers under csrc/: the public header include/cpflow_amd.h is not part of any kernel)
+    stamp, tag = os.path.join(JIT_DIR, '.stamp'), str(max(os.path.getmtime(d) for d in DEPS if d.endswith('.h') and os.sep + 'csrc' + os.sep in d))
     if not os.path.exists(stamp) or open(stamp).read() != tag:
         for f in os.listdir(JIT_DIR):
             if f.endswith('.hsaco') or '.tmp' in f:

@@ -92,7 +92,13 @@ double cpf_plan_flops_per_sample_step(const cpf_plan* plan);
 
 /* ---- device-pointer API (all d_* are device pointers on the plan's device;
  *      stream is a hipStream_t passed as void*, NULL = default stream; calls are
- *      asynchronous with respect to the host) ---- */
+ *      asynchronous with respect to the host, except that the first launch of a plan on a
+ *      stream - and any later one with more samples than that stream has seen - allocates the
+ *      per-stream scratch of the kernels that keep per-block tables in scalar registers and
+ *      waits for the stream's earlier work.  Launches of ONE plan on different streams may
+ *      overlap on the device (each stream has its own scratch); issue them from one host thread
+ *      at a time: the plan builds its per-circuit tables lazily and keeps the last launch's
+ *      timing events and variant name) ---- */
 
 /* Initial angles (main.py:541-548): rows [first, first+count) of the
  * num_samples_total x P matrix jax would draw from PRNGKey(seed).
