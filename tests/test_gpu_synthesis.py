@@ -366,15 +366,15 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
 
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without torchrun starts two ranks itself (here both on the one GPU: CPF_ONE_DEVICE=1 ->
-    gloo) and reports n_gpus = 2 with the whole-job sample count."""
+    gloo) and reports n_gpus = 2 with the whole-job sample count; with --strong-ref the line also carries the one-GPU time of the whole job."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
     env['CPF_ONE_DEVICE'] = '1'
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--samples-per-gpu', '256'],
-                         env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--samples-per-gpu', '256',
+                          '--strong-ref'], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and '512 total' in line['config']['workload']
@@ -382,6 +382,9 @@ def test_bench_launches_its_own_ranks():
     # the line describes the job torch.distributed ran: here gloo, two ranks, both on the box's one GPU
     di = line['distributed']
     assert di['backend'] == 'gloo' and di['world_size'] == 2 and [e['rank'] for e in di['ranks']] == [0, 1] and di['distinct_devices'] == 1
+    # --strong-ref: rank 0 also ran the whole job's 512 samples on its one GPU (the strong-scaling reference of the same line)
+    sr = line['strong_ref']
+    assert sr['samples'] == 512 and sr['ms_per_step_one_gpu'] > 0 and abs(sr['strong_scaling_efficiency'] - sr['ms_per_step_one_gpu'] / (2 * line['ms_per_step'])) < 1e-9
 
 
 def _score(cz_passed, S):
