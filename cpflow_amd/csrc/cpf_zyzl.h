@@ -380,7 +380,14 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                         t.mm[k] = m; t.vv[k] = v;
                         t.th[k] = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), t.th[k]);
                     }
-                    fast_sincos(k == 3 ? t.th[k] : 0.5f * t.th[k], t.cs[k][1], t.cs[k][0]);
+                }
+                {   // (cos, sin) of the four angles on packed arithmetic, two per call (bit-identical to fast_sincos per half); slot 3
+                    // is a CP angle (full angle), the others are half angles; an absent angle is 0 -> (1, 0)
+                    f2 s01, c01, s23, c23;
+                    fast_sincos2(f2{0.5f * t.th[0], 0.5f * t.th[1]}, s01, c01);
+                    fast_sincos2(f2{0.5f * t.th[2], t.th[3]}, s23, c23);
+                    t.cs[0][0] = c01.x; t.cs[0][1] = s01.x; t.cs[1][0] = c01.y; t.cs[1][1] = s01.y;
+                    t.cs[2][0] = c23.x; t.cs[2][1] = s23.x; t.cs[3][0] = c23.y; t.cs[3][1] = s23.y;
                 }
                 if (t.kind == 0) {
                     if (ENT == 0 && t.pj[3] >= 0 && a.use_reg) {
