@@ -763,6 +763,9 @@ ZYZ_CASES = [
     ([[5, 4], [4, 5], [0, 5], [4, 1]], 6, 'zyxz', 'cp', '2', 'jit'),         # both qubits of a block on lanes; 4 rotation letters (kinds from the records)
     ([[0, 1], [4, 2]], 3, 'xyz', 'cp', '1', 'jit'),                          # qubits no block touches, fewer blocks than qubits
     ([[2, 5], [5, 3]], 1, 'xyz', 'cp', '1', 'jit'),                          # a single block
+    ([[i, (i + 1) % 6] for i in range(6)], 4, 'xyz', 'cp', '1', 'jit'),      # fewer blocks than one layer (its own period): qubit 5 untouched, qubit 4 touched once
+    ([[i, (i + 1) % 6] for i in range(6)], 7, 'xyz', 'cp', '1', 'aot'),      # one layer and one block
+    ([[0, 5], [2, 3], [4, 1], [5, 4], [3, 5]], 7, 'zx', 'cz', '1', 'jit'),   # CZ blocks on 6 qubits, the lane qubit in three of five pairs
 ]
 
 
