@@ -437,7 +437,10 @@ cpf_jit::Spec dense_jit_spec(int nq, int lw, int rot, const std::vector<int>& ud
 bool dense_wanted(const cpf_plan* plan, int mode) {
     if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->NQ < 4 || plan->K < 1 || plan->n_rot > 8) return false;
     const TuneVal e = tuning("CPF_DENSE");
-    return e ? e[0] != '0' : plan->NQ == 6;
+    // default: 6 qubits; and 4 / 5 qubits with more than three rotation letters, which the gate-by-gate kernels only serve through the
+    // generic per-gate kernel (same box, 'zyxz': 4 qubits, 12 blocks, 2048 samples 142.2 -> 26.9 ms; 5 qubits, 16 blocks, 1000 samples
+    // 258.6 -> 42.5; 4 qubits, 100 samples 112.9 -> 20.2)
+    return e ? e[0] != '0' : (plan->NQ == 6 || plan->n_rot > 3);
 }
 int dense_lw(const cpf_plan* plan, int64_t S) {
     const TuneVal w = tuning("CPF_DENSE_LW");
@@ -880,7 +883,7 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     // against 28.6 relabelled), hence the choice per launch.
     pl->has_relabel = (pl->NQ == 4 || pl->NQ == 5) && pl->n == pl->NQ;
     { const TuneVal e = tuning("CPF_RELABEL"); if (e && e[0] == '0') pl->has_relabel = false; }      // A/B and tests
-    { const TuneVal e = tuning("CPF_DENSE"); if (e && e[0] == '1') pl->has_relabel = false; }        // the dense kernel has its own qubit moves
+    { const TuneVal e = tuning("CPF_DENSE"); if (e ? e[0] == '1' : pl->n_rot > 3) pl->has_relabel = false; }        // the dense layout has its own qubit moves
     for (int which = 0; which < 2; which++) {
         cpf_plan::Labelling& lb = pl->lab[which];
         lb.qperm.resize((size_t)pl->n);

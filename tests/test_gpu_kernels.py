@@ -990,3 +990,22 @@ def test_zyz_form_with_four_waves_per_sample_matches_oracle(layer, K, rot, ent, 
     frozen[1::2, ::5] = 1
     outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
     assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
+
+
+@pytest.mark.parametrize('layer,K,S', [([[0, 1], [1, 2], [2, 3]], 9, 5), ([[0, 1], [1, 2], [2, 3], [3, 4]], 7, 1100)])
+def test_four_rotation_letters_take_the_dense_layout_zyz_kernel(layer, K, S):
+    """More than three rotation letters: the gate-by-gate kernels are specialised on at most three, so 4- and 5-qubit templates
+    with longer strings run on the dense-layout ZYZ-form kernel (kinds read from the records) instead of the generic per-gate
+    kernel - against the float64 oracle."""
+    n = max(max(p) for p in layer) + 1
+    target = _rand_unitary(n, 21)
+    T = 10
+    kw = dict(num_gd_iterations=T, r=0.003)
+    orc = Oracle(layer, K, target, 'zyxz', **kw)
+    eng = _engine(layer, K, target, 'zyxz', **kw)
+    init = orc.initial_angles(6, S)
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant().startswith('zyz/jit(hipcc)'), eng.last_variant()
+    ref = orc.run(init[:5], np.float64, keep_history=True)
+    assert np.abs(out['history_regloss'][:5] - ref['history_loss']).max() < 2e-5
+    assert np.abs(out['history_params'][:5] - ref['history_params']).max() < 2e-4
