@@ -1,7 +1,7 @@
 // cpflow_amd: the ZYZ form of the entangling blocks (cpf_zyz_math.h, tools/zyz_model.py) on the gate-by-gate layout - one wave
-// per sample, 3..5 qubits.
+// per sample (4 and 5 qubits; 3 on request), or four waves per sample for launches of at most two waves per SIMD (5 qubits).
 //
-// Layout Lay<NQ, 0> (cpf_device.h): the first NLR row qubits sit on DPP-reachable lane bits, the others on register bits
+// Layout Lay<NQ, LW> (cpf_device.h): the first NLR row qubits sit on DPP-reachable lane bits, the others on register bits
 // (E = 2^NRR amplitudes per lane); the plan relabels the problem's qubits so that the most-used ones are register qubits.
 // A block is  x <- d_ab x  (one merged phase per amplitude of the pair, read from a per-block LDS table; a lane qubit's bit
 // selects the lane's entries) followed by the two unnormalised real stages (a, b) <- (a - t b, b + t a):
@@ -235,8 +235,8 @@ __device__ __forceinline__ void zl_product(f2 (&x)[L::E], f2 base, const F& fac)
     }, typename make_iseq<L::NRR>::type{});
 }
 
-// Items: one per side (i = 2 b + side < 2 K), then one per qubit (i = 2 K + q).  Item i belongs to lane i mod 64, slot i / 64 (NSLOT
-// slots per lane, a template argument), and that lane OWNS the item's angles - a side's rotation angles (and, for side 0, the
+// Items: one per side (i = 2 b + side < 2 K), then one per qubit (i = 2 K + q).  Item i belongs to thread i mod THREADS of the
+// sample's 64 or 256, slot i / THREADS (NSLOT slots per lane, a template argument), and that lane OWNS the item's angles - a side's rotation angles (and, for side 0, the
 // block's CP angle), a qubit's three surface angles: Adam state, (cos, sin), the side's factors and the gradients the chain phase
 // produces all stay in the owner's registers; only what other lanes need crosses LDS (the side records, the per-block tables, the
 // surface matrices, the reduced sums).
