@@ -44,11 +44,37 @@ def gate_matrix(name, params):
     raise TypeError(f"Gate '{name}' not implemented.")
 
 
+_SQ = math.sqrt(0.5)
+
+
+def _g1(name, params):
+    """One-qubit gate as a tuple (u00, u01, u10, u11) of Python complex numbers: the run-merging
+    loops below multiply hundreds of 2x2 matrices per circuit, where numpy's call overhead dominates."""
+    if name == 'h':
+        return (_SQ, _SQ, _SQ, -_SQ)
+    a = float(params[0]) / 2
+    c, s = math.cos(a), math.sin(a)
+    if name == 'rx':
+        return (c, -1j * s, -1j * s, c)
+    if name == 'ry':
+        return (c, -s, s, c)
+    if name == 'rz':
+        return (complex(c, -s), 0.0, 0.0, complex(c, s))
+    raise TypeError(f"Gate '{name}' not implemented.")
+
+
+def _mul2(g, h):
+    return (g[0] * h[0] + g[1] * h[2], g[0] * h[1] + g[1] * h[3],
+            g[2] * h[0] + g[3] * h[2], g[2] * h[1] + g[3] * h[3])
+
+
 def zxz_angles(u):
-    """(z1, x, z2) with u = phase * Rz(z2) Rx(x) Rz(z1)."""
-    u = np.asarray(u, dtype=complex)
-    u = u / cmath.sqrt(np.linalg.det(u))
-    alpha, beta = u[0, 0], u[1, 0]
+    """(z1, x, z2) with u = phase * Rz(z2) Rx(x) Rz(z1); u is a 2x2 array or a (u00, u01, u10, u11) tuple."""
+    if not isinstance(u, tuple):
+        u = np.asarray(u, dtype=complex)
+        u = (complex(u[0, 0]), complex(u[0, 1]), complex(u[1, 0]), complex(u[1, 1]))
+    root = cmath.sqrt(u[0] * u[3] - u[1] * u[2])
+    alpha, beta = u[0] / root, u[2] / root
     x = 2 * math.atan2(abs(beta), abs(alpha))
     if abs(beta) < 1e-12:
         return -2 * cmath.phase(alpha), 0.0, 0.0
@@ -119,14 +145,38 @@ class Circuit:
         return max(level) if level else 0
 
     def unitary(self):
+        """Runs of one-qubit gates are multiplied as 2x2 matrices and applied once, when a
+        two-qubit gate (or the end) needs the qubit; CZ / CP scale and CX swaps slices in place."""
         n = self.num_qubits
-        u = np.eye(2 ** n, dtype=complex).reshape([2] * n + [2 ** n])
+        dim = 2 ** n
+        u = np.eye(dim, dtype=complex)
+        pending = [None] * n
+
+        def flush(q):
+            if pending[q] is None:
+                return u
+            g = np.array(pending[q], dtype=complex).reshape(2, 2)
+            pending[q] = None
+            return np.matmul(g, u.reshape(2 ** q, 2, -1)).reshape(dim, dim)
+
         for name, qubits, params in self.data:
-            k = len(qubits)
-            g = gate_matrix(name, params).reshape([2] * (2 * k))
-            u = np.tensordot(g, u, axes=[list(range(k, 2 * k)), list(qubits)])
-            u = np.moveaxis(u, list(range(k)), list(qubits))
-        return u.reshape(2 ** n, 2 ** n)
+            if len(qubits) == 1:
+                q, g = qubits[0], _g1(name, params)
+                pending[q] = g if pending[q] is None else _mul2(g, pending[q])
+                continue
+            q0, q1 = qubits
+            u = flush(q0)
+            u = flush(q1)
+            lo, hi = min(q0, q1), max(q0, q1)
+            v = u.reshape(2 ** lo, 2, 2 ** (hi - lo - 1), 2, -1)      # axes 1, 3 = qubits lo, hi
+            if name == 'cx':
+                w = v[:, 1] if q0 == lo else v[:, :, :, 1]            # control = 1
+                w[...] = np.flip(w, axis=2 if q0 == lo else 1).copy()  # exchange the target's two slices
+            else:
+                v[:, 1, :, 1, :] *= -1.0 if name == 'cz' else cmath.exp(1j * float(params[0]))
+        for q in range(n):
+            u = flush(q)
+        return u
 
     # ---- rewriting
     def cp_to_cz(self, cp_threshold=0.2):
@@ -164,9 +214,8 @@ class Circuit:
 
         for name, qubits, params in self.data:
             if len(qubits) == 1:
-                q = qubits[0]
-                g = gate_matrix(name, params)
-                pending[q] = g if pending[q] is None else g @ pending[q]
+                q, g = qubits[0], _g1(name, params)
+                pending[q] = g if pending[q] is None else _mul2(g, pending[q])
             else:
                 for q in qubits:
                     flush(q)

@@ -92,6 +92,43 @@ def test_circuit_ir():
     assert d.depth(['cz']) == 4 and d.count_ops() == {'cz': 4, 'rx': 1}
 
 
+def test_circuit_unitary_equals_gate_by_gate_kronecker_products():
+    """Circuit.unitary() merges one-qubit runs and applies CZ / CP / CX on slices; the plain
+    definition (every gate embedded with Kronecker products, qubit 0 = MSB) is the check."""
+    from cpflow_amd.circuit import gate_matrix
+    rng = np.random.default_rng(5)
+
+    def embed(n, name, qubits, params):
+        g = gate_matrix(name, params)
+        if len(qubits) == 1:
+            return np.kron(np.kron(np.eye(2 ** qubits[0]), g), np.eye(2 ** (n - 1 - qubits[0])))
+        full = np.zeros((2 ** n, 2 ** n), dtype=complex)
+        a, b = qubits
+        for col in range(2 ** n):
+            bits = [(col >> (n - 1 - q)) & 1 for q in range(n)]
+            for out in range(4):
+                amp = g[out, 2 * bits[a] + bits[b]]
+                if amp != 0:
+                    ob = list(bits)
+                    ob[a], ob[b] = out >> 1, out & 1
+                    full[sum(v << (n - 1 - q) for q, v in enumerate(ob)), col] += amp
+        return full
+
+    for n in (1, 2, 3, 4, 5):
+        for _ in range(6):
+            qc, want = Circuit(n), np.eye(2 ** n, dtype=complex)
+            for _ in range(40):
+                kind = rng.integers(0, 7 if n > 1 else 4)
+                if kind < 4:
+                    gate = (('rx', 'ry', 'rz', 'h')[kind], (int(rng.integers(0, n)),), (rng.normal(),) if kind < 3 else ())
+                else:
+                    a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+                    gate = (('cz', 'cx', 'cp')[kind - 4], (a, b), (rng.normal(),) if kind == 6 else ())
+                qc.append(*gate)
+                want = embed(n, *gate) @ want
+            assert np.abs(qc.unitary() - want).max() < 1e-12
+
+
 def test_project_cp_angles():
     mask = np.array([0, 0, 1, 0, 1, 1, 1])
     ang = np.array([1, 2, 0.1, 3, np.pi + 0.15, 1.5, -0.05 + 4 * np.pi], dtype=np.float32)
