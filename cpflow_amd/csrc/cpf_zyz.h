@@ -47,8 +47,8 @@ struct ZyzLds {
     __host__ __device__ ZyzLds(int P, int G, int K, int nq, int wps) {
         rec = PEN_FLOATS;                      // G x {cos, sin, code, -}
         side = rec + 4 * G;                    // 2 K x {t, sc, l0, l1, f, m}
-        binfo = side + 16 * K;                 // K x {cacb, d0}
-        surfm = up4(binfo + 2 * K);            // nq x 2x2 complex
+        binfo = side + 16 * K;                 // K x {cacb, d0, 1 / phi^2, -}
+        surfm = binfo + 4 * K;                 // nq x 2x2 complex
         lfin = surfm + 8 * nq;                 // nq x (l0, l1)
         msf = lfin + 4 * nq;                   // nq flip parities
         fw = up4(msf + nq);                    // 4 x 64 flip bits
@@ -77,10 +77,15 @@ __device__ __forceinline__ void zyz_load_tab(const float* gp, ZyzTab& g) {
 // current table here, the caller issues the next block's loads right after it (cpf_dense.h dense_touch_s)
 __device__ __forceinline__ void zyz_touch(const ZyzTab& g) { asm volatile("" :: "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt)); }
 
+#ifndef CPF_ZYZ_LAYER_SCALE
+#define CPF_ZYZ_LAYER_SCALE 1    // A/B: 0 = every block multiplies by its own real scale d_0 (three packed multiplies per group, block and step more)
+#endif
 #ifndef CPF_ZYZ_FWD2
 #define CPF_ZYZ_FWD2 1           // A/B: 0 = one group of four amplitudes per asm statement in the forward sweep
 #endif
-template <int E, int RA, int RB>
+// SC: the block multiplies by its real scale d_0 (the last block of a layer, which carries the layer's; the others do not: a
+// layer's blocks leave psi and the cotangent off by known real factors in between, see "build B")
+template <int E, int RA, int RB, bool SC>
 __device__ __forceinline__ void zyz_apply(f2 (&x)[E], const ZyzTab& g) {
     // the groups of the block in pairs: two groups per statement, their instructions alternating
     int prev = -1;
@@ -89,16 +94,19 @@ __device__ __forceinline__ void zyz_apply(f2 (&x)[E], const ZyzTab& g) {
         if (e & ((1 << RA) | (1 << RB))) continue;
         if (CPF_ZYZ_FWD2 != 0 && E >= 8) {
             if (prev < 0) { prev = e; continue; }
-            zyz_group_fwd2(x[prev], x[prev | (1 << RA)], x[prev | (1 << RB)], x[prev | (1 << RA) | (1 << RB)],
-                           x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+            if constexpr (SC) zyz_group_fwd2(x[prev], x[prev | (1 << RA)], x[prev | (1 << RB)], x[prev | (1 << RA) | (1 << RB)],
+                                             x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+            else zyz_group_fwd2_ns(x[prev], x[prev | (1 << RA)], x[prev | (1 << RB)], x[prev | (1 << RA) | (1 << RB)],
+                                   x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
             prev = -1;
         } else {
-            zyz_group_fwd(x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+            if constexpr (SC) zyz_group_fwd(x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
+            else zyz_group_fwd_ns(x[e], x[e | (1 << RA)], x[e | (1 << RB)], x[e | (1 << RA) | (1 << RB)], g);
         }
     }
 }
 // backward pass of one block; d8 receives this thread's shares {Px, Py, Pz of the lo qubit, the same of the hi qubit, S11, -}
-template <int E, int RA, int RB>
+template <int E, int RA, int RB, bool SC>
 __device__ __forceinline__ void zyz_backward(f2 (&p)[E], f2 (&c)[E], const ZyzTab& g, float (&d8)[8]) {
     ZyzAcc a;
     bool first = true;
@@ -106,8 +114,13 @@ __device__ __forceinline__ void zyz_backward(f2 (&p)[E], f2 (&c)[E], const ZyzTa
     for (int e = 0; e < E; e++) {
         if (e & ((1 << RA) | (1 << RB))) continue;
         const int e1 = e | (1 << RA), e2 = e | (1 << RB), e3 = e1 | e2;
-        if (first) zyz_group_bwd_first(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
-        else zyz_group_bwd(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
+        if constexpr (SC) {
+            if (first) zyz_group_bwd_first(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
+            else zyz_group_bwd(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
+        } else {
+            if (first) zyz_group_bwd_first_ns(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
+            else zyz_group_bwd_ns(p[e], p[e1], p[e2], p[e3], c[e], c[e1], c[e2], c[e3], a, g);
+        }
         first = false;
     }
     const f2 zl = a.ta + a.tb, zh = a.ta - a.tb;
@@ -265,15 +278,23 @@ __device__ __forceinline__ void zyz_body(const ZyzArgs& za) {
                 if (wu >= 0) { pu = load_side(wu); pu.m = su.m ^ su.f; }
                 if (wd >= 0) { pd = load_side(wd); pd.m = sd.m ^ sd.f; }
                 const float4 r0 = rec[g0];
+                // The real scale d_0 = sc_u sc_d of a block is applied once per LAYER: the layer's last block (and the circuit's
+                // last block) multiplies by the product over its layer so far, the others by nothing.  In between psi runs ahead
+                // by 1 / (d_0 of the blocks passed) in the forward sweep - at most 2 per block - and psi and the cotangent fall
+                // behind by phi = the product of d_0 up to and including the block whose sums are being taken in the backward
+                // sweep: the chain phase divides the block's sums by phi^2.
+                float pre = 1.f;
+                for (int i = CPF_ZYZ_LAYER_SCALE ? b - b % LL : b; i <= b; i++) pre *= smem[lds.side + 16 * i + 1] * smem[lds.side + 16 * i + 9];
+                const bool carries = !CPF_ZYZ_LAYER_SCALE || (b % LL == LL - 1) || b == K - 1;
                 float out[10];
-                const int cacb = zyz::block_table(out, su, sd, wu >= 0, pu, wd >= 0, pd, r0.x, r0.y, (z & 256) != 0);
+                const int cacb = zyz::block_table(out, su, sd, wu >= 0, pu, wd >= 0, pd, r0.x, r0.y, (z & 256) != 0, carries ? pre : 1.f);
                 float* gt = za.tab + ((size_t)s_idx * K + b) * ZYZ_TAB_FLOATS;
                 *reinterpret_cast<float4*>(gt) = make_float4(out[0], out[1], out[2], out[3]);
                 *reinterpret_cast<float4*>(gt + 4) = make_float4(out[4], out[5], out[6], out[7]);
                 *reinterpret_cast<float2*>(gt + 8) = make_float2(out[8], out[9]);
                 smem[lds.side + 16 * b + 7] = __int_as_float(su.m);
                 smem[lds.side + 16 * b + 15] = __int_as_float(sd.m);
-                *reinterpret_cast<float2*>(smem + lds.binfo + 2 * b) = make_float2(__int_as_float(cacb), out[0]);
+                *reinterpret_cast<float4*>(smem + lds.binfo + 4 * b) = make_float4(__int_as_float(cacb), su.sc * sd.sc, carries ? 1.f : __builtin_amdgcn_rcpf(pre * pre), 0.f);
             } else {
                 const int q = w - K;
                 const ZyzSideInfo* iq = za.sides + 2 * K + q;
@@ -334,7 +355,7 @@ __device__ __forceinline__ void zyz_body(const ZyzArgs& za) {
                         if constexpr (J + 1 < LL) { if (!TAIL || b + 1 < K) zyz_load_tab(gsample + ZYZ_TAB_FLOATS * (b + 1), gnext); }
                         if constexpr (ent.x >= 0 && !KEPT) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);
                         if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
-                        zyz_apply<E, RA, RB>(psi, g);
+                        zyz_apply<E, RA, RB, !CPF_ZYZ_LAYER_SCALE || TAIL || J == LL - 1>(psi, g);
                         if constexpr (ent.y >= 0) swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi);
                         if constexpr (ent.x >= 0) {
                             if (!KEEP || b + 1 >= K) swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi);     // the last block of the circuit always exchanges back
@@ -459,7 +480,7 @@ __device__ __forceinline__ void zyz_body(const ZyzArgs& za) {
                     }
                     if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
                     float d8[8];
-                    zyz_backward<E, RA, RB>(psi, cot, gc, d8);
+                    zyz_backward<E, RA, RB, !CPF_ZYZ_LAYER_SCALE || TAIL || J == LL - 1>(psi, cot, gc, d8);
                     reduce8_rows<true>(d8, sums_w + 32 * b, lane, surf_dst);
                     if constexpr (ent.y >= 0) { swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(psi); swap_lane_reg<E, (ent.y >> 8), (ent.y & 255)>(cot); }
                     if constexpr (ent.x >= 0 && !KEEP) { swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(psi); swap_lane_reg<E, (ent.x >> 8), (ent.x & 255)>(cot); }
@@ -500,7 +521,8 @@ __device__ __forceinline__ void zyz_body(const ZyzArgs& za) {
             if (w < 2 * K) {
                 const int b = w >> 1, side = w & 1, z = blk[4 * b + 2], g0 = blk[4 * b + 3];
                 const int kx = ((side == 0) == ((z & 256) != 0)) ? 0 : 3;           // this side's qubit sits on the pair's lo / hi register bit
-                const float px = slab_sum(lds.sums, K * 32, b, kx), py = slab_sum(lds.sums, K * 32, b, kx + 1), pz = slab_sum(lds.sums, K * 32, b, kx + 2);
+                const float4 bi = *reinterpret_cast<const float4*>(smem + lds.binfo + 4 * b);          // bi.z: 1 / phi^2 of the block's sums (build B)
+                const float px = bi.z * slab_sum(lds.sums, K * 32, b, kx), py = bi.z * slab_sum(lds.sums, K * 32, b, kx + 1), pz = bi.z * slab_sum(lds.sums, K * 32, b, kx + 2);
                 const zyz::Side sd = load_side(w);
                 float gpart[8];
                 zyz::chain_side<ROT>(gpart, px, py, pz, sd, block_rec(g0), NR, side);
@@ -519,11 +541,10 @@ __device__ __forceinline__ void zyz_body(const ZyzArgs& za) {
                         if (wp < 0) pzq[s] = slab_sum(lds.gsurf, NBATCH * 32, (3 * q + 2) >> 3, (3 * q + 2) & 7);
                         else {
                             const int zp = blk[4 * (wp >> 1) + 2];
-                            pzq[s] = slab_sum(lds.sums, K * 32, wp >> 1, ((((wp & 1) == 0) == ((zp & 256) != 0)) ? 0 : 3) + 2);
+                            pzq[s] = smem[lds.binfo + 4 * (wp >> 1) + 2] * slab_sum(lds.sums, K * 32, wp >> 1, ((((wp & 1) == 0) == ((zp & 256) != 0)) ? 0 : 3) + 2);
                         }
                     }
-                    const float2 bi = *reinterpret_cast<const float2*>(smem + lds.binfo + 2 * b);
-                    gw[g0] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], __float_as_int(bi.x), bi.y);
+                    gw[g0] = zyz::chain_cp(bi.z * slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], __float_as_int(bi.x), bi.y);
                 }
             } else {
                 const int q = w - 2 * K;

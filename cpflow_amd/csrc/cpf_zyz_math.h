@@ -105,12 +105,12 @@ CPF_ZHD Side side_build(const Rec& rec, int n_rot, int side) {
 
 // What a block's sweep needs, in the kernel's index order k = 2 * hi + lo (lo / hi: the pair's lower / higher register bit;
 // up_low: the placement's first qubit sits on the lower one):
-//   out[0] = d_0 (real: the scale sc_u sc_d), out[1] = 0, out[2 k], out[2 k + 1] = d_k (k = 1, 2, 3), out[8] = t_lo, out[9] = t_hi.
+//   out[0] = d_0 (real: the scale sc_u sc_d, or `scale`), out[1] = 0, out[2 k], out[2 k + 1] = d_k (k = 1, 2, 3), out[8] = t_lo, out[9] = t_hi.
 // up, dn: the block's sides with f and m set.  has_pu / has_pd: a previous block touches the qubit; pu / pd: that block's side
 // (its m set too).  (cc, sc): cos / sin of the CP angle, (-1, 0) for CZ.  Returns (ca | cb << 1): the amplitude of the pair
 // (up bit ca, dn bit cb) that carries the entangler's phase in the held frame.
 CPF_ZHD int block_table(float* out, const Side& up, const Side& dn, bool has_pu, const Side& pu, bool has_pd, const Side& pd,
-                        float cc, float sc, bool up_low) {
+                        float cc, float sc, bool up_low, float scale = -1.f) {
     C2 eu[2], ed[2];
     {
         const C2 r1 = cconj(cmul(up.l0, up.l1));
@@ -137,7 +137,9 @@ CPF_ZHD int block_table(float* out, const Side& up, const Side& dn, bool has_pu,
             if (a == ca && b == cb) v = cmul(v, lam);
             d[2 * a + b] = v;
         }
-    const float s = up.sc * dn.sc;
+    // scale >= 0: the modulus the caller wants on the phases instead of this block's own sc_u sc_d (cpf_zyz.h: the last block of a
+    // layer carries the scale of the whole layer, the others 1)
+    const float s = scale >= 0.f ? scale : up.sc * dn.sc;
     const C2 g = cscale(cconj(d[0]), s);                       // every factor has unit modulus: conj(d_00) is its inverse
     out[0] = s; out[1] = 0.f;
 #pragma unroll

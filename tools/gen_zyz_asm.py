@@ -43,23 +43,32 @@ def stage(dst_a, dst_b, a, b, tt, hi, sign):
             f'v_pk_fma_f32 {dst_b}, {tt}, {a}, {b} {plus if sign > 0 else minus}']
 
 
-def forward():
+def forward(scale=True):
+    """scale=False (a block whose real scale another block of its layer carries): no x_0 <- d_0 x_0; the lo stage then reads x_0 in
+    its input register and the group's x_0 ENDS in that register (the wrapper returns it from there)."""
     o, i = ['%0', '%1', '%2', '%3'], ['%4', '%5', '%6', '%7']
     sd, d, tt = '%8', [None, '%9', '%10', '%11'], '%12'
     m1, m3, m2 = cmul(o[1], o[1], d[1], i[1], False), cmul(o[3], o[3], d[3], i[3], False), cmul(o[2], o[2], d[2], i[2], False)
-    lines = [m1[0], m3[0], m2[0], f'v_pk_mul_f32 {o[0]}, {sd}, {i[0]} op_sel_hi:[0,1]', m1[1], m3[1], m2[1]]
-    l01, l23 = stage(i[0], i[1], o[0], o[1], tt, False, 1), stage(i[2], i[3], o[2], o[3], tt, False, 1)
-    lines += [l01[0], l23[0], l01[1], l23[1]]
-    h02, h13 = stage(o[0], o[2], i[0], i[2], tt, True, 1), stage(o[1], o[3], i[1], i[3], tt, True, 1)
-    lines += [h02[0], h02[1], h13[0], h13[1]]
-    assert len(lines) == 15
+    if scale:
+        lines = [m1[0], m3[0], m2[0], f'v_pk_mul_f32 {o[0]}, {sd}, {i[0]} op_sel_hi:[0,1]', m1[1], m3[1], m2[1]]
+        l01, l23 = stage(i[0], i[1], o[0], o[1], tt, False, 1), stage(i[2], i[3], o[2], o[3], tt, False, 1)
+        lines += [l01[0], l23[0], l01[1], l23[1]]
+        h02, h13 = stage(o[0], o[2], i[0], i[2], tt, True, 1), stage(o[1], o[3], i[1], i[3], tt, True, 1)
+        lines += [h02[0], h02[1], h13[0], h13[1]]
+    else:
+        lines = [m1[0], m3[0], m2[0], m1[1], m3[1], m2[1]]
+        l01, l23 = stage(o[0], i[1], i[0], o[1], tt, False, 1), stage(i[2], i[3], o[2], o[3], tt, False, 1)
+        lines += [l01[0], l01[1], l23[0], l23[1]]
+        h02, h13 = stage(i[0], o[2], o[0], i[2], tt, True, 1), stage(o[1], o[3], i[1], i[3], tt, True, 1)
+        lines += [h02[0], h02[1], h13[0], h13[1]]
+    assert len(lines) == (15 if scale else 14)
     return lines
 
 
-def forward2():
+def forward2(scale=True):
     """two groups in one statement, instruction by instruction in turn: every result is read four to eight instructions later.
     Operands: %0-%3 o (group A), %4-%7 x (A), %8-%11 o (B), %12-%15 x (B), %16-%20 table"""
-    a = forward()
+    a = forward(scale)
     ren_a = {f'%{k}': f'%{k}' for k in range(8)}
     ren_a.update({'%8': '%16', '%9': '%17', '%10': '%18', '%11': '%19', '%12': '%20'})
     ren_b = {f'%{k}': f'%{k + 8}' for k in range(8)}
@@ -86,7 +95,7 @@ def acc(dst, a, b, swap, neg, first):
     return f'v_pk_fma_f32 {dst}, {a}, {b}, {dst} {sel}{ng}'.rstrip()
 
 
-def backward(first):
+def backward(first, scale=True):
     p, c = ['%0', '%1', '%2', '%3'], ['%4', '%5', '%6', '%7']
     AXlo, AYlo, AXhi, AYhi, TA, TB, CC = '%8', '%9', '%10', '%11', '%12', '%13', '%14'
     u = ['%15', '%16', '%17', '%18']
@@ -118,8 +127,8 @@ def backward(first):
         lines += [m1[0], m3[0], m2[0]]
         if x is p:                # the |11> sum reads c_3 (written three instructions ago) and p_3 before conj(d_3) lands in it
             lines.append(acc(CC, c[3], p[3], True, False, first))
-        lines += [f'v_pk_mul_f32 {x[0]}, {sd}, {x[0]} op_sel_hi:[0,1]', m1[1], m3[1], m2[1]]
-    assert len(lines) == 51
+        lines += ([f'v_pk_mul_f32 {x[0]}, {sd}, {x[0]} op_sel_hi:[0,1]'] if scale else []) + [m1[1], m3[1], m2[1]]
+    assert len(lines) == (51 if scale else 49)
     return lines
 
 
@@ -158,6 +167,25 @@ __device__ __forceinline__ void zyz_group_fwd2(f2& x0, f2& x1, f2& x2, f2& x3, f
         : "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt));
     x0 = o0; x1 = o1; x2 = o2; x3 = o3; y0 = q0; y1 = q1; y2 = q2; y3 = q3;
 }
+// the same without the real scale d_0 (a block whose scale the last block of its layer carries, cpf_zyz.h): 14 instructions; x_0 is
+// left in its own register
+__device__ __forceinline__ void zyz_group_fwd_ns(f2& x0, f2& x1, f2& x2, f2& x3, const ZyzTab& g) {
+    f2 o0, o1, o2, o3;
+    asm(
+%s
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
+        : "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt));
+    x1 = o1; x2 = o2; x3 = o3;
+}
+__device__ __forceinline__ void zyz_group_fwd2_ns(f2& x0, f2& x1, f2& x2, f2& x3, f2& y0, f2& y1, f2& y2, f2& y3, const ZyzTab& g) {
+    f2 o0, o1, o2, o3, q0, q1, q2, q3;
+    asm(
+%s
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3),
+          "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3)
+        : "s"(g.sd), "s"(g.d1), "s"(g.d2), "s"(g.d3), "s"(g.tt));
+    x1 = o1; x2 = o2; x3 = o3; y1 = q1; y2 = q2; y3 = q3;
+}
 #define CPF_ZYZ_BWD_OPERANDS(ACC)                                                                                                  \\
         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3),                                          \\
           ACC(a.axlo), ACC(a.aylo), ACC(a.axhi), ACC(a.ayhi), ACC(a.ta), ACC(a.tb), ACC(a.cc),                                    \\
@@ -179,12 +207,27 @@ __device__ __forceinline__ void zyz_group_bwd(f2& p0, f2& p1, f2& p2, f2& p3, f2
         CPF_ZYZ_BWD_OPERANDS(CPF_ZYZ_ACC_RW));
 }
 
+// without the real scale: 49 instructions
+__device__ __forceinline__ void zyz_group_bwd_first_ns(f2& p0, f2& p1, f2& p2, f2& p3, f2& c0, f2& c1, f2& c2, f2& c3, ZyzAcc& a, const ZyzTab& g) {
+    f2 u0, u1, u2, u3;
+    asm(
+%s
+        CPF_ZYZ_BWD_OPERANDS(CPF_ZYZ_ACC_W));
+}
+__device__ __forceinline__ void zyz_group_bwd_ns(f2& p0, f2& p1, f2& p2, f2& p3, f2& c0, f2& c1, f2& c2, f2& c3, ZyzAcc& a, const ZyzTab& g) {
+    f2 u0, u1, u2, u3;
+    asm(
+%s
+        CPF_ZYZ_BWD_OPERANDS(CPF_ZYZ_ACC_RW));
+}
+
 }  // namespace cpf
 '''
 
 
 def render():
-    return HEADER % (c_string(forward()), c_string(forward2()), c_string(backward(True)), c_string(backward(False)))
+    return HEADER % (c_string(forward()), c_string(forward2()), c_string(forward(False)), c_string(forward2(False)),
+                     c_string(backward(True)), c_string(backward(False)), c_string(backward(True, False)), c_string(backward(False, False)))
 
 
 if __name__ == '__main__':

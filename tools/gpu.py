@@ -180,7 +180,7 @@ def cmd_fuzz(args):
             layer[0] = [int(rng.integers(n - 1)), n - 1]     # the layer defines n (topology.py:36-38)
         if n == 3 and rng.random() < 0.5:                    # the reference's own layers: block-count-specialised kernels from the shipped cache
             layer = [[[0, 1], [1, 2]], [[0, 1], [0, 2], [1, 2]]][int(rng.integers(2))]
-        K = int(rng.integers(2, 27)) if n == 3 else int(rng.integers(2, 9))
+        K = int(rng.integers(2, 27)) if n == 3 else int(rng.integers(2, int(os.environ.get('FUZZ_KMAX', '9'))))
         rot = ROTS[int(rng.integers(len(ROTS)))]
         ent = str(rng.choice(['cp', 'cp', 'cp', 'cz', 'cx']))
         target = rand_u(n, rng)
