@@ -26,7 +26,7 @@ def shim(tmp_path_factory):
     lib.zm_chain_cp.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
     lib.zm_chain_side.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.zm_chain_surface.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
-    lib.zm_block_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]
+    lib.zm_block_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_float]
     return lib
 
 
@@ -63,8 +63,10 @@ def loss_of(U, V):
     return 1 - abs(np.sum(U * np.conj(V))) ** 2 / U.shape[0] ** 2
 
 
-def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=lambda b: b % 2 == 0):
-    """loss and gradient the way cpf_zyz.h computes them; the build / chain algebra through the C++ header"""
+def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=lambda b: b % 2 == 0, layer_len=None):
+    """loss and gradient the way cpf_zyz.h computes them; the build / chain algebra through the C++ header.
+    layer_len: the real scale once per layer (cpf_zyz.h "build B") - the phases of a block have unit modulus unless it is the last of
+    its layer or of the circuit, which carries the product of d_0 over its layer so far; a block's sums are divided by phi^2."""
     N, K, nr = 1 << n, len(placements), len(rots)
     nb = 2 * nr + (1 if ent == 'cp' else 0)
     th32 = theta.astype(np.float32)
@@ -93,11 +95,21 @@ def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=l
             pend[q] ^= int(sides[b, s, 6])
     m_surf = pend
     tabs, cacb = np.zeros((K, 10), np.float32), [0] * K
+    d0 = (sides[:, 0, 1] * sides[:, 1, 1]).astype(np.float32)
+    invphi2 = np.ones(K)
     for b in range(K):
         pu = None if prev[b][0] is None else P(sides[prev[b][0]])
         pd = None if prev[b][1] is None else P(sides[prev[b][1]])
-        cacb[b] = shim.zm_block_table(P(tabs[b]), P(sides[b, 0]), P(sides[b, 1]), pu, pd, recs[b][0, 0], recs[b][0, 1], int(up_low_of(b)))
+        scale = -1.0
+        if layer_len:
+            pre = np.float32(np.prod(d0[b - b % layer_len:b + 1]))
+            carries = b % layer_len == layer_len - 1 or b == K - 1
+            scale = float(pre) if carries else 1.0
+            invphi2[b] = 1.0 if carries else 1.0 / float(pre) ** 2
+        cacb[b] = shim.zm_block_table(P(tabs[b]), P(sides[b, 0]), P(sides[b, 1]), pu, pd, recs[b][0, 0], recs[b][0, 1], int(up_low_of(b)), scale)
         assert tabs[b, 1] == 0
+        mods = np.hypot(tabs[b, 2:8:2], tabs[b, 3:8:2])
+        assert np.abs(mods - tabs[b, 0]).max() < 1e-6 and abs(tabs[b, 0] - (scale if layer_len else d0[b])) < 1e-7
 
     def kidx(b, r):          # kernel index of row r within block b's pair: 2 hi + lo
         up, dn = placements[b]
@@ -137,10 +149,10 @@ def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=l
     Pxyz, S11 = np.zeros((K, 2, 3)), np.zeros(K)
     for b in range(K - 1, -1, -1):
         for s, q in enumerate(placements[b]):
-            Pxyz[b, s] = [gen(q, k, W, U) for k in range(3)]
+            Pxyz[b, s] = [invphi2[b] * gen(q, k, W, U) for k in range(3)]
         U, W = ystage(b, -1) @ U, ystage(b, -1) @ W
         mask = np.array([kidx(b, r) == 3 for r in range(N)])
-        S11[b] = np.sum(np.conj(W[mask]) * U[mask]).imag
+        S11[b] = invphi2[b] * np.sum(np.conj(W[mask]) * U[mask]).imag
         U, W = np.conj(dvec(b))[:, None] * U, np.conj(dvec(b))[:, None] * W
     Psurf = np.array([[gen(q, k, W, U) for k in range(3)] for q in range(n)])
     grad = np.zeros_like(theta)
@@ -151,7 +163,7 @@ def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=l
             grad[3 * n + nb * b + s:3 * n + nb * b + 2 * nr:2] = g
         if ent == 'cp':
             pz = [Psurf[placements[b][s], 2] if prev[b][s] is None else Pxyz[prev[b][s][0], prev[b][s][1], 2] for s in (0, 1)]
-            grad[3 * n + nb * b + nb - 1] = shim.zm_chain_cp(float(S11[b]), float(pz[0]), float(pz[1]), cacb[b], float(tabs[b, 0]))
+            grad[3 * n + nb * b + nb - 1] = shim.zm_chain_cp(float(S11[b]), float(pz[0]), float(pz[1]), cacb[b], float(d0[b]))
     for q in range(n):
         g = np.zeros(3, np.float32)
         shim.zm_chain_surface(P(g), *[float(v) for v in Psurf[q]], m_surf[q], P(surf_cs[q]))
@@ -159,10 +171,10 @@ def kernel_play(shim, n, placements, theta, V, rots, ent, xyz=False, up_low_of=l
     return loss, grad, int(sides[:, :, 6].sum())
 
 
-def _check(shim, n, placements, theta, rots, ent, rng, xyz=False):
+def _check(shim, n, placements, theta, rots, ent, rng, xyz=False, layer_len=None):
     a = rng.normal(size=(1 << n, 1 << n)) + 1j * rng.normal(size=(1 << n, 1 << n))
     V = np.linalg.qr(a)[0]
-    loss, grad, flips = kernel_play(shim, n, placements, theta, V, rots, ent, xyz)
+    loss, grad, flips = kernel_play(shim, n, placements, theta, V, rots, ent, xyz, layer_len=layer_len)
     assert abs(loss - loss_of(reference_unitary(n, placements, theta, rots, ent), V)) < 3e-6
     fd = np.zeros_like(theta)
     for j in range(len(theta)):
@@ -185,6 +197,22 @@ def test_random_circuits_loss_and_gradient(shim, rots, ent):
         theta = rng.uniform(-2 * np.pi, 2 * np.pi, 3 * n + nb * len(placements))
         flips += _check(shim, n, placements, theta, rots, ent, rng)
     assert flips > 0                                   # the flipped branch was exercised
+
+
+@pytest.mark.parametrize('layer_len', [1, 2, 3, 5])
+def test_real_scale_once_per_layer(shim, layer_len):
+    """cpf_zyz.h applies a block's real scale d_0 once per layer: unit-modulus phases, the last block of a layer (or of the
+    circuit: the block counts below leave truncated last layers) carries the layer's product, sums divided by phi^2."""
+    rng = np.random.default_rng(40 + layer_len)
+    flips = 0
+    for rots, ent, K in (('xyz', 'cp', 7), ('xz', 'cz', 6), ('xyz', 'cp', 11)):
+        n = 4
+        layer = [tuple(int(q) for q in rng.choice(n, 2, replace=False)) for _ in range(layer_len)]
+        placements = [layer[b % layer_len] for b in range(K)]
+        nb = 2 * len(rots) + (1 if ent == 'cp' else 0)
+        theta = rng.uniform(-2 * np.pi, 2 * np.pi, 3 * n + nb * K)
+        flips += _check(shim, n, placements, theta, rots, ent, rng, layer_len=layer_len)
+    assert flips > 0
 
 
 @pytest.mark.parametrize('case', ['identity', 'flip', 'diagonal', 'mixed'])

@@ -12,9 +12,10 @@ static Side get(const float* o) { Side s; s.t = o[0]; s.sc = o[1]; s.l0 = c2(o[2
 extern "C" void zm_side_build(const float* rec, int n_rot, int side, int xyz, float* out) {
     put(xyz ? side_build<8451>(ArrRec{rec}, 3, side) : side_build<0>(ArrRec{rec}, n_rot, side), out);
 }
-extern "C" int zm_block_table(float* out, const float* up, const float* dn, const float* pu, const float* pd, float cc, float sc, int up_low) {
+// scale < 0: the block's own sc_up sc_dn on the phases; otherwise the modulus given (cpf_zyz.h: the real scale once per layer)
+extern "C" int zm_block_table(float* out, const float* up, const float* dn, const float* pu, const float* pd, float cc, float sc, int up_low, float scale) {
     const Side none = {};
-    return block_table(out, get(up), get(dn), pu != nullptr, pu ? get(pu) : none, pd != nullptr, pd ? get(pd) : none, cc, sc, up_low != 0);
+    return block_table(out, get(up), get(dn), pu != nullptr, pu ? get(pu) : none, pd != nullptr, pd ? get(pd) : none, cc, sc, up_low != 0, scale);
 }
 extern "C" void zm_chain_side(float* grad, float px, float py, float pz, const float* sd, const float* rec, int n_rot, int side, int xyz) {
     if (xyz) chain_side<8451>(grad, px, py, pz, get(sd), ArrRec{rec}, 3, side);
