@@ -22,6 +22,10 @@ after A by the left diagonal) dotted with the generator carried back through the
 the |11> sum and - when flips moved its phase to another amplitude of the pair - the z sums of the previous blocks on the two
 qubits (sum over everything of Im(conj(w) psi) is zero for every loss kind, so the other three amplitudes follow).
 
+The dense-layout kernel additionally applies the real scale once per LAYER instead of once per block (unit-modulus phases, the
+layer's last block carries the product, every block's sums divided by the square of the factor psi and the cotangent are off by
+there): that bookkeeping is modelled, through the C++ header, by tests/test_zyz_math.py::test_real_scale_once_per_layer.
+
     python tools/zyz_model.py        # prints the worst deviations; exits non-zero above 1e-9 / 1e-6
 """
 import sys
