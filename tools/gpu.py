@@ -7,6 +7,7 @@
     python tools/gpu.py ablib libA.so libB.so [cfg]            same-box A/B of two builds (alternating processes, CPF_LIB)
     python tools/gpu.py agree <KNOB> [cfg2|cfg3]               two settings of a knob: agreement on short runs + timing over S
     python tools/gpu.py fuzz [n_cases] [seed]                  random layers / block counts / rotation strings vs the f64 oracle
+                                                               (env FUZZ_NS=4,5,6: qubit counts to draw from; FUZZ_KMAX: block counts for n >= 4)
     python tools/gpu.py fix4                                   4-qubit golden fixture: pass set of each kernel variant
     python tools/gpu.py stamps                                 per-phase cycle shares (library built with -DCPF_STAMPS)
     python tools/gpu.py static-e2e                             wall time of Synthesize.static() end to end
@@ -172,7 +173,7 @@ def cmd_fuzz(args):
                 dict(CPF_PSTORE='1', CPF_KSPEC='0', CPF_JIT_K='0'), dict(CPF_SPLIT='0')]
     bad, t0 = 0, time.time()
     for _case in range(N):
-        n = int(rng.choice([2, 3, 3, 3, 4, 4, 5, 6]))
+        n = int(rng.choice([int(x) for x in os.environ['FUZZ_NS'].split(',')] if os.environ.get('FUZZ_NS') else [2, 3, 3, 3, 4, 4, 5, 6]))
         pairs = [list(p) for p in itertools.permutations(range(n), 2)]
         LL = min(int(rng.integers(1, 4)), len(pairs))
         layer = [pairs[i] for i in rng.choice(len(pairs), LL, replace=False)]
@@ -186,6 +187,8 @@ def cmd_fuzz(args):
         target = rand_u(n, rng)
         T = 6
         S = 1100 if n in (4, 5) and rng.random() < 0.5 else 3          # 4 / 5 qubits: one wave per sample (relabelled qubits) or four
+        if n == 6 and rng.random() < 0.5:
+            S = 600                                                    # 6 qubits: two waves per sample (above 512 samples) or four
         if n == 3:
             S = int(rng.choice([3, 300, 700, 2100]))                   # 3 qubits: one sample per CU / stored states / saturated
         r = float(rng.choice([0.0, 0.004]))
