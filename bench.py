@@ -114,6 +114,17 @@ def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
                       f'{"-march=native" if lib_path else "portable -O3"}), {dt:.1f} s'}
 
 
+def executed_flops(variant, num_qubits, num_blocks, algorithmic):
+    """Approximate flops the kernel EXECUTES per sample-step, for the ZYZ-form kernels only (None otherwise: the gate-by-gate
+    kernels execute SURVEY's count and more).  The generated group routines (cpf_zyz_asm.h) spend 15 + 51 packed instructions per
+    four amplitudes and block = 13 + 47 flop per amplitude with a packed multiply counted as 2 and a packed FMA as 4; the
+    surface gates and per-step phases are left at SURVEY's figure."""
+    if not variant.startswith(('zyz/', 'zyzl/')):
+        return None
+    n2 = float(1 << (2 * num_qubits))
+    return algorithmic - 3.0 * n2 * 32.0 * num_blocks + n2 * 60.0 * num_blocks
+
+
 def other_configs(workloads, TemplateEngine, torch, launches=3):
     """The other BASELINE configurations' per-GPU shares (cfg3: 512 samples, cfg4: 2048, cfg5: 1024) measured in this same
     process after the headline run: one warm-up and `launches` timed launches each (HIP events on the launch stream), so
@@ -136,6 +147,10 @@ def other_configs(workloads, TemplateEngine, torch, launches=3):
                           'kernel': eng.last_variant(), 'kernel_ms': ms, 'kernel_ms_all': all_ms,
                           'sample_steps_per_s': S * wl.num_gd_iterations / (ms * 1e-3), 'tflops': tf, 'frac': tf / FP32_PEAK_TFLOPS,
                           'flop_per_sample_step': eng.flops_per_sample_step, 'passed_entry_loss': int(out['passed'].sum())}
+            ex = executed_flops(eng.last_variant(), wl.num_qubits, wl.num_cp_gates, eng.flops_per_sample_step)
+            if ex is not None:          # 'frac' prices SURVEY's dense-4x4 count; the ZYZ form executes fewer flops for the same result
+                rows[name]['flop_executed_per_sample_step'] = ex
+                rows[name]['frac_executed'] = rows[name]['frac'] * ex / eng.flops_per_sample_step
             eng.close()
         except Exception as e:          # reported, never required
             rows[name] = {'error': str(e)[:300]}
@@ -293,6 +308,10 @@ def main():
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,
                     'frac': alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        ex = executed_flops(eng.last_variant(), wl.num_qubits, K, flops)
+        if ex is not None:
+            line['roofline']['flop_executed_per_sample_step'] = ex
+            line['roofline']['frac_executed'] = line['roofline']['frac'] * ex / flops
         line['distributed'] = dist_info
         if strong_ref:
             # strong efficiency = t(1 GPU, all samples) / (N x t(N GPUs, all samples)); the weak one is the driver's from its per-N values
