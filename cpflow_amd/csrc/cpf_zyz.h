@@ -9,6 +9,8 @@
 //     forward     x_k <- d_k x_k (d_0 real), two stages (a, b) <- (a - t b, b + t a)                         15 instructions
 //     backward    the same in reverse on psi and on the cotangent, 20 for the generator sums + 1              51
 // i.e. 66 instead of 128, and 7 sums per block cross the lanes instead of a 32-value environment.
+// The real scale d_0 is applied by the last block of each layer only, for the whole layer ("build B" below): the other blocks run
+// the 14- / 49-instruction forms of the two routines.
 //
 // Layout, exchanges of lane qubits against register qubits, the layer as a template argument and the scalar-register table
 // (a global scratch written by the build phase, read back with scalar loads) are those of cpf_dense.h: DLay<NQ, LW>,
