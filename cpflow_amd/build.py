@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_dense_math.h', 'cpf_dense_asm.h', 'cpf_dense_aot.h', 'cpf_dense_aot.hip', 'cpf_zyz.h', 'cpf_zyzl.h', 'cpf_zyz_math.h', 'cpf_zyz_asm.h', 'cpf_zyz_aot.h', 'cpf_zyz_aot.hip', 'cpf_jit.h')
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_dense_math.h', 'cpf_dense_asm.h', 'cpf_dense_aot.h', 'cpf_dense_aot.hip', 'cpf_zyz.h', 'cpf_zyzl.h', 'cpf_zyz3.h', 'cpf_zyz_math.h', 'cpf_zyz_asm.h', 'cpf_zyz_aot.h', 'cpf_zyz_aot.hip', 'cpf_jit.h')
                 if os.path.exists(os.path.join(HERE, 'csrc', h))] + [os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
 JIT_DIR = os.path.join(HERE, 'jit_cache')      # shipped code objects of runtime-specialised kernels (git-ignored, travels with gpurun)
 OUT = os.path.join(HERE, 'libcpflow_amd.so')

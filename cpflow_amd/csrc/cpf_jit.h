@@ -141,7 +141,7 @@ inline Code build(const Spec& sp, bool cached_only = false) {
     Code out;
     const std::string inc = lib_dir() + "/csrc";
     std::string hdrs;
-    for (const char* h : {"cpf_device.h", "cpf_blocks.h", "cpf_layered.h", "cpf_split.h", "cpf_dense.h", "cpf_dense_math.h", "cpf_dense_asm.h", "cpf_zyz.h", "cpf_zyz_math.h", "cpf_zyz_asm.h", "cpf_zyzl.h"}) hdrs += read_file(inc + "/" + h);
+    for (const char* h : {"cpf_device.h", "cpf_blocks.h", "cpf_layered.h", "cpf_split.h", "cpf_dense.h", "cpf_dense_math.h", "cpf_dense_asm.h", "cpf_zyz.h", "cpf_zyz_math.h", "cpf_zyz_asm.h", "cpf_zyzl.h", "cpf_zyz3.h"}) hdrs += read_file(inc + "/" + h);
     if (hdrs.size() < 1000) { out.error = "kernel headers not found under " + inc; return out; }
     // one extern "C" kernel per translation unit: its name needs no lowering, whichever compiler builds it
     const std::string src = "#include \"" + sp.header + "\"\nextern \"C\" __global__ __launch_bounds__(" + std::to_string(sp.threads) +

@@ -154,6 +154,38 @@ CPF_ZHD int block_table(float* out, const Side& up, const Side& dn, bool has_pu,
     return ca | (cb << 1);
 }
 
+// ---- The same table in two lane-parallel steps (the two-ended 3-qubit kernel, cpf_zyz3.h: one lane per side, then one lane per
+// table entry).  side_epair: what one SIDE contributes to its block's merged phases - (left factors the previous block on the qubit
+// left behind) x (this side's right factors), the entries exchanged by the pending parities - and the bit of the pair's amplitude
+// that carries the entangler's phase in the held frame.  The previous side's parity is this side's xor its own flip (the sides
+// later than the previous one are this one and those later than it).
+struct EPair { C2 e0, e1; int c; };
+CPF_ZHD EPair side_epair(const Side& sd, bool has_prev, C2 pl0, C2 pl1) {
+    const C2 r1 = cconj(cmul(sd.l0, sd.l1));
+    C2 p0 = c2(1.f, 0.f), p1 = c2(1.f, 0.f);
+    if (has_prev) { const int mp = sd.m ^ sd.f; p0 = mp ? pl1 : pl0; p1 = mp ? pl0 : pl1; }
+    EPair e;
+    e.e0 = sd.m ? cmul(p0, r1) : p0;
+    e.e1 = sd.m ? p1 : cmul(p1, r1);
+    e.c = 1 ^ sd.m ^ sd.f;
+    return e;
+}
+// entry (a, b) of the block's table (a: the up qubit's bit, b: the dn qubit's): out[0], out[1] = d_ab with the global phase divided
+// out and the real scale s = sc_u sc_d folded in (entry (0, 0): (s, 0) exactly), out[2], out[3] = the tangents of the two stages
+// signed for a lane whose bits are (a, b): x <- x + out[2] x[partner on up], then the same with out[3] on dn.
+CPF_ZHD void table_entry(float* out, int a, int b, const EPair& eu, const EPair& ed, float tu, float scu, float td, float scd, float cc, float sc) {
+    const C2 lam = c2(cc, sc);
+    C2 d00 = cmul(eu.e0, ed.e0);
+    if (eu.c == 0 && ed.c == 0) d00 = cmul(d00, lam);
+    C2 d = cmul(a ? eu.e1 : eu.e0, b ? ed.e1 : ed.e0);
+    if (a == eu.c && b == ed.c) d = cmul(d, lam);
+    const float s = scu * scd;
+    const C2 v = cmul(d, cscale(cconj(d00), s));
+    const bool first = a == 0 && b == 0;
+    out[0] = first ? s : v.re; out[1] = first ? 0.f : v.im;
+    out[2] = a ? tu : -tu; out[3] = b ? td : -td;
+}
+
 // so3(R)^T P for R = exp(-i a sigma_axis / 2), (c, s) = (cos a/2, sin a/2): the two other components rotate by -a
 CPF_ZHD void so3_inv(int axis, float c, float s, float (&P)[3]) {
     const float ca = c * c - s * s, sa = 2.f * c * s;

@@ -23,6 +23,7 @@
 #include "cpf_dense_aot.h"
 #include "cpf_zyz.h"
 #include "cpf_zyzl.h"
+#include "cpf_zyz3.h"
 #include "cpf_zyz_aot.h"
 #include "cpf_jit.h"
 
@@ -763,6 +764,46 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
     return e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
 }
 
+// ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut and layer are compile-time constants of every instance.
+// The cut M (blocks swept by wave A; wave B also owns every angle): CPF_ZYZ3_M overrides the default.
+int zyz3_cut(const cpf_plan* plan) {
+    const int K = plan->K;
+    int m = (3 * K + 2) / 4;
+    { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
+    return std::max(1, std::min(K - 1, m));
+}
+cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M}, ud), 128};
+    { const TuneVal e = tuning("CPF_ZYZ3_STAMPS"); if (e && e[0] == '1') spec.flags = {"-DCPF_STAMPS"}; }      // diagnostics: per-phase cycle sums (tools/gpu.py stamps)
+    return spec;
+}
+bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) {
+    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || a.loss_kind == 2) return false;
+    if (!cpf::zyz3_supported(plan->K, plan->n_rot) || plan->entangler == CPF_ENTANGLER_CX) return false;
+    if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
+    if ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) return false;
+    const TuneVal e = tuning("CPF_ZYZ3");
+    return e && e[0] == '1';
+}
+bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (!zyz3_wanted(plan, a) || !plan->use_jit) return false;
+    const int M = zyz3_cut(plan);
+    const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(dense_rot_code(plan), plan->K, M, plan->layer_ud));
+    if (!k.fn) {
+        plan->jit_note = k.error;
+        if (k.error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", k.error.c_str()); return true; }
+        return false;
+    }
+    const size_t lds = (size_t)cpf::zyz3_lds_floats(plan->K) * sizeof(float);
+    if (!module_lds_opt_in(k.fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the two-ended ZYZ-form kernel"; return false; }
+    cpf::KArgs args = a;
+    void* params[] = {&args};
+    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, 128, 1, 1, (unsigned)lds, stream, params, nullptr);
+    plan->variant = "zyz3/jit(" + k.backend + ") waves=2 K cut=" + std::to_string(M);
+    *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
+    return true;
+}
+
 // 3 qubits: a two-ended kernel specialised on the block count, when cpflow_amd/jit_cache/ (or the private cache) holds
 // one for this shape - python -m cpflow_amd.build --precompile ships them for the block counts an adaptive search over
 // the reference's 3-qubit layers visits.  Nothing is compiled here: a miss falls through to the kernels that read the
@@ -845,6 +886,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     // 0. a shipped 3-qubit kernel specialised on the block count; 1. ahead-of-time layered kernel (3 qubits, the
     // reference's own layers); 2. runtime-specialised layered kernel; 3. generic per-gate kernel
     { const TuneVal e = tuning("CPF_ZYZL"); if (e && e[0] == '1' && plan->NQ == 3 && try_zyzl(plan, a, lw, S, stream, &rc)) return rc; }
+    if (try_zyz3(plan, a, S, stream, &rc)) return rc;
     if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_zyz(plan, a, S, stream, &rc)) return rc;
@@ -926,7 +968,7 @@ const char* cpf_last_error(void) { return g_err; }
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
                                         "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
-                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3"};
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_STAMPS"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {

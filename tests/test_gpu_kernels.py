@@ -1009,3 +1009,77 @@ def test_four_rotation_letters_take_the_dense_layout_zyz_kernel(layer, K, S):
     ref = orc.run(init[:5], np.float64, keep_history=True)
     assert np.abs(out['history_regloss'][:5] - ref['history_loss']).max() < 2e-5
     assert np.abs(out['history_params'][:5] - ref['history_params']).max() < 2e-4
+
+
+ZYZ3_CASES = [
+    ([[0, 1], [1, 2]], 12, 'xyz', 'cp', None),                # config 2's shape
+    ([[0, 1], [0, 2], [1, 2]], 16, 'xyz', 'cp', None),        # config 3's shape: a truncated last layer
+    ([[0, 1], [1, 2]], 7, 'xz', 'cp', 3),                     # two letters, the cut inside a layer
+    ([[2, 0], [1, 2], [0, 1]], 7, 'xyz', 'cp', 1),            # twisted placements, one block in wave A
+    ([[1, 0], [2, 0]], 5, 'y', 'cp', 4),                      # one letter, one block in wave B
+    ([[1, 2], [0, 1]], 6, 'zyx', 'cz', None),                 # CZ blocks, a string that does not end in z
+    ([[0, 2]], 2, 'xyz', 'cp', None),                         # an untouched qubit, the smallest block count
+    ([[0, 1], [0, 2], [1, 2]], 30, 'xz', 'cp', None),         # 63 items: every owner lane but one
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('layer,K,rot,ent,cut', ZYZ3_CASES)
+def test_two_ended_zyz_kernel_matches_oracle(layer, K, rot, ent, cut, tune):
+    """The two-ended ZYZ-form kernel of 3 qubits (cpf_zyz3.h: wave A applies blocks 0 .. M-1 to the product state of the surface
+    gates, wave B un-applies blocks K-1 .. M from the target and owns every angle; generator sums from one live and one stored
+    matrix per slice, added row by row in LDS) against the float64 oracle over a short Adam run with history, penalty on,
+    frozen mask and degenerate starts (identity rotations, exact flips), and against the gate-by-gate two-ended kernel."""
+    target = _rand_unitary(3, 22)
+    T, S = 14, 6
+    tune.set('CPF_ZYZ3', '1')
+    if cut is not None:
+        tune.set('CPF_ZYZ3_M', str(cut))
+    kw = dict(entangler=ent, num_gd_iterations=T, r=0.004)
+    orc = Oracle(layer, K, target, rot, **kw)
+    eng = _engine(layer, K, target, rot, **kw)
+    init = orc.initial_angles(9, S)
+    nb = 2 * len(rot) + (1 if ent == 'cp' else 0)
+    blk = init[:, 9:].reshape(S, K, nb)
+    blk[4, :, :2 * len(rot)] = 0.0
+    blk[5, :, :2 * len(rot)] = np.float32(np.pi) * np.random.default_rng(1).integers(-1, 3, (K, 2 * len(rot)))
+    out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
+    assert eng.last_variant().startswith('zyz3/'), eng.last_variant()
+    if cut is not None:
+        assert eng.last_variant().endswith(f'cut={cut}'), eng.last_variant()
+    ref = orc.run(init, np.float64, keep_history=True)
+    tol = 1e-5 if K <= 16 else 3e-5
+    assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < tol / 2
+    assert np.abs(out['history_params'] - ref['history_params'])[:4, :2].max() < 3 * tol
+    assert np.median(np.abs(out['history_regloss'] - ref['history_loss'])[:4, :10].max(axis=1)) < tol
+    assert np.abs(out['history_regloss'] - ref['history_loss'])[:4].max() < 5 * tol
+    for s in (4, 5):                                  # degenerate starts: the loss of every visited iterate, whatever the path
+        for t in (0, 1, T - 1):
+            lg = orc.loss_grad(out['history_params'][s, t][None], np.float64)
+            assert abs(out['history_regloss'][s, t] - lg['regloss'][0]) < tol
+    assert (out['params'][:, 0] == init).all()
+    assert np.abs(out['reg'][:4, 0] - ref['reg'][:4, 0]).max() < 1e-6
+    assert np.abs(out['reg'][:4, 1] - ref['reg'][:4, 1]).max() < tol / 10
+    assert (out['cz'][:4] == ref['cz'][:4]).all()
+    hp, best = out['history_params'], out['params'][:, 1]
+    for s in range(S):
+        assert any((best[s] == hp[s, t]).all() for t in range(T))
+    frozen = np.zeros((S, orc.P), np.uint8)
+    frozen[:, ::3] = 1
+    outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen, keep_history=True).items()}
+    assert eng.last_variant().startswith('zyz3/')
+    hpf = outf['history_params']
+    assert (hpf[:, :, ::3] == init[:, None, ::3]).all() and (hpf[:, -1, 1::3] != init[:, 1::3]).any()
+    reff = Oracle(layer, K, target, rot, frozen_mask=frozen[0], **kw).run(init, np.float64, keep_history=True)
+    assert np.median(np.abs(outf['history_regloss'] - reff['history_loss'])[:4, :10].max(axis=1)) < tol
+    tune.set('CPF_ZYZ3', '0')                         # the gate-by-gate kernels on the same inputs
+    eng0 = _engine(layer, K, target, rot, **kw)
+    out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init).items()}
+    assert not eng0.last_variant().startswith('zyz3/'), eng0.last_variant()
+    assert np.abs(out['regloss'] - out0['regloss'])[:4].max() < 5 * tol
+    # zero iterations: the loss of the initial angles only
+    eng1 = _engine(layer, K, target, rot, entangler=ent, num_gd_iterations=0, r=0.004)
+    tune.set('CPF_ZYZ3', '1')
+    out1 = {k: v.cpu().numpy() for k, v in eng1.optimize(init).items()}
+    assert eng1.last_variant().startswith('zyz3/'), eng1.last_variant()
+    assert np.abs(out1['regloss'][:, 0] - out['regloss'][:, 0]).max() == 0 and (out1['params'][:, 1] == init).all()

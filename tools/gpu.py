@@ -50,7 +50,7 @@ def configs():
 
 
 TUNING = ('CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_GROUP', 'CPF_DENSE', 'CPF_DENSE_LW',
-          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3')
+          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3', 'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_STAMPS')
 
 
 def sync_tuning():
@@ -250,10 +250,13 @@ def cmd_stamps(args):
     eng, Ss = engine(cfg, T=500)
     T = 500
     out = eng.optimize(eng.initial_angles(0, int(os.environ.get('S', str(Ss[0])))), keep_history=True)
-    split = eng.last_variant().startswith('split')
+    split = eng.last_variant().startswith(('split', 'zyz3'))
     h = out['history_regloss'][0, :16].cpu().numpy().astype(np.float64)
     names = (['forward half', 'wait for other wave', 'loss/track', 'backward half', 'wait for other wave', 'owner', 'wait (owner)', 'loop top'] if split else
              ['surface fwd', 'blocks fwd', 'loss/track', 'blocks bwd', 'surface bwd', 'owner (Adam, sincos, penalty)', '-', 'loop top'])
+    if eng.last_variant().startswith('zyz3'):
+        names = ['owner / build', 'wait (tables)', 'forward half', 'wait for other wave', 'loss/track', 'gradient half', 'wait for other wave', 'row sums + chain']
+    print(eng.last_variant())
     for w in ((0, 1) if split else (0,)):
         st = h[8 * w:8 * w + 8]
         print('wave', 'AB'[w], 'total', st.sum() / T, 'cycles/step')
