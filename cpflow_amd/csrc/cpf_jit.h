@@ -240,7 +240,8 @@ inline std::mutex& table_mutex() { static std::mutex m; return m; }
 // (a kernel that is an optional upgrade over one the library already holds); its misses are remembered apart from the
 // failures of a full build, so that a later full build of the same body is still attempted.
 inline const Kernel& get(int device, const Spec& sp, bool cached_only = false) {
-    const std::string key = "dev" + std::to_string(device) + ":" + sp.body;
+    std::string key = "dev" + std::to_string(device) + ":" + sp.body;
+    for (const std::string& f : sp.flags) key += " " + f;
     std::lock_guard<std::mutex> lock(table_mutex());
     auto it = table().find(key);
     if (it != table().end()) return it->second;

@@ -775,6 +775,16 @@ int zyz3_cut(const cpf_plan* plan) {
 cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, const std::vector<int>& ud) {
     cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M}, ud), 128};
     { const TuneVal e = tuning("CPF_ZYZ3_STAMPS"); if (e && e[0] == '1') spec.flags = {"-DCPF_STAMPS"}; }      // diagnostics: per-phase cycle sums (tools/gpu.py stamps)
+    {   // A/B builds: extra -D flags, separated by spaces
+        const TuneVal e = tuning("CPF_ZYZ3_DEFS");
+        size_t i = 0;
+        while (e && i < e.s.size()) {
+            size_t j = e.s.find(' ', i);
+            if (j == std::string::npos) j = e.s.size();
+            if (j > i) spec.flags.push_back(e.s.substr(i, j - i));
+            i = j + 1;
+        }
+    }
     return spec;
 }
 bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) {
@@ -968,7 +978,7 @@ const char* cpf_last_error(void) { return g_err; }
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
                                         "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
-                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_STAMPS"};
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {

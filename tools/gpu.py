@@ -50,7 +50,7 @@ def configs():
 
 
 TUNING = ('CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_GROUP', 'CPF_DENSE', 'CPF_DENSE_LW',
-          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3', 'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_STAMPS')
+          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3', 'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_STAMPS', 'CPF_ZYZ3_DEFS')
 
 
 def sync_tuning():
@@ -115,7 +115,7 @@ def cmd_knobs(args):
     for _ in range(5):
         for c in combos:
             for kv in c.split(','):
-                k, v = kv.split('=')
+                k, v = kv.split('=', 1)
                 os.environ[k] = v
             sync_tuning()
             out = eng.optimize(init)
