@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'cpflow_amd.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_dense_math.h', 'cpf_dense_asm.h', 'cpf_dense_aot.h', 'cpf_dense_aot.hip', 'cpf_zyz.h', 'cpf_zyzl.h', 'cpf_zyz3.h', 'cpf_zyz_math.h', 'cpf_zyz_asm.h', 'cpf_zyz_aot.h', 'cpf_zyz_aot.hip', 'cpf_jit.h')
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', h) for h in ('cpf_device.h', 'cpf_blocks.h', 'cpf_layered.h', 'cpf_split.h', 'cpf_dense.h', 'cpf_dense_math.h', 'cpf_dense_asm.h', 'cpf_dense_aot.h', 'cpf_dense_aot.hip', 'cpf_zyz.h', 'cpf_zyzl.h', 'cpf_zyz3.h', 'cpf_zyz_math.h', 'cpf_zyz_asm.h', 'cpf_zyz_aot.h', 'cpf_zyz_aot.hip', 'cpf_zyz3_aot.h', 'cpf_zyz3_aot.hip', 'cpf_jit.h')
                 if os.path.exists(os.path.join(HERE, 'csrc', h))] + [os.path.join(os.path.dirname(HERE), 'include', 'cpflow_amd.h')]
 JIT_DIR = os.path.join(HERE, 'jit_cache')      # shipped code objects of runtime-specialised kernels (git-ignored, travels with gpurun)
 OUT = os.path.join(HERE, 'libcpflow_amd.so')
@@ -27,6 +27,7 @@ def up_to_date():
 # alloca-promotion limits (cpf_dense_aot.h), which the other kernels are not built with
 DENSE_SRC = os.path.join(HERE, 'csrc', 'cpf_dense_aot.hip')
 ZYZ_SRC = os.path.join(HERE, 'csrc', 'cpf_zyz_aot.hip')
+ZYZ3_SRC = os.path.join(HERE, 'csrc', 'cpf_zyz3_aot.hip')
 DENSE_FLAGS = ['-mllvm', '-amdgpu-promote-alloca-to-vector-max-regs=128', '-mllvm', '-amdgpu-promote-alloca-to-vector-vgpr-ratio=1']
 
 
@@ -35,7 +36,7 @@ def build(force=False, verbose=False):
         return OUT
     cflags = [f for f in FLAGS if f != '-shared']
     objs = [(SRC, os.path.join(HERE, 'csrc', 'cpflow_amd.o'), []), (DENSE_SRC, os.path.join(HERE, 'csrc', 'cpf_dense_aot.o'), DENSE_FLAGS),
-            (ZYZ_SRC, os.path.join(HERE, 'csrc', 'cpf_zyz_aot.o'), DENSE_FLAGS)]
+            (ZYZ_SRC, os.path.join(HERE, 'csrc', 'cpf_zyz_aot.o'), DENSE_FLAGS), (ZYZ3_SRC, os.path.join(HERE, 'csrc', 'cpf_zyz3_aot.o'), [])]
     procs = []
     for src, obj, extra in objs:          # the two units compile side by side
         cmd = [HIPCC] + cflags + extra + ['-c', '-o', obj, src]
@@ -58,7 +59,7 @@ def build_variant(name, defines=(), verbose=False):
     out = os.path.join(HERE, f'libcpflow_amd.{name}.so')
     cflags = [f for f in FLAGS if f != '-shared'] + [f'-D{d}' for d in defines]
     objs = [(SRC, os.path.join(HERE, 'csrc', f'cpflow_amd.{name}.o'), []), (DENSE_SRC, os.path.join(HERE, 'csrc', f'cpf_dense_aot.{name}.o'), DENSE_FLAGS),
-            (ZYZ_SRC, os.path.join(HERE, 'csrc', f'cpf_zyz_aot.{name}.o'), DENSE_FLAGS)]
+            (ZYZ_SRC, os.path.join(HERE, 'csrc', f'cpf_zyz_aot.{name}.o'), DENSE_FLAGS), (ZYZ3_SRC, os.path.join(HERE, 'csrc', f'cpf_zyz3_aot.{name}.o'), [])]
     procs = [subprocess.Popen([HIPCC] + cflags + extra + ['-c', '-o', obj, src]) for src, obj, extra in objs]
     for p in procs:
         if p.wait():

@@ -70,7 +70,10 @@ CPF_ZHD Side side_build(const Rec& rec, int n_rot, int side) {
         rec(1 + 2 * i + side, c, s, kind);
         kind = rotc_kind<ROT>(i, kind);
         C2 pn, qn;
-        if (kind == Z_RX) {                  // [[c, -is], [-is, c]]
+        if (i == 0) {                        // the first rotation acts on the identity: its first column, without the products by 0 and 1
+            pn = c2(c, kind == Z_RZ ? -s : 0.f);
+            qn = kind == Z_RX ? c2(0.f, -s) : (kind == Z_RY ? c2(s, 0.f) : c2(0.f, 0.f));
+        } else if (kind == Z_RX) {           // [[c, -is], [-is, c]]
             pn = c2(c * p.re + s * q.im, c * p.im - s * q.re);
             qn = c2(c * q.re + s * p.im, c * q.im - s * p.re);
         } else if (kind == Z_RY) {           // [[c, -s], [s, c]]

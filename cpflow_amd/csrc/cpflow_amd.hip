@@ -24,6 +24,7 @@
 #include "cpf_zyz.h"
 #include "cpf_zyzl.h"
 #include "cpf_zyz3.h"
+#include "cpf_zyz3_aot.h"
 #include "cpf_zyz_aot.h"
 #include "cpf_jit.h"
 
@@ -765,10 +766,12 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 }
 
 // ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut and layer are compile-time constants of every instance.
-// The cut M (blocks swept by wave A; wave B also owns every angle): CPF_ZYZ3_M overrides the default.
+// The cut M (blocks swept by wave A; wave B also owns every angle): measured best near 0.45 K (config 2's shape, 1024 samples:
+// 5.36 / 5.48 / 5.62 / 6.19 ms for 5 / 6 / 7 / 8 of 12; config 3's share 5.82 / 5.76 / 6.22 for 6 / 7 / 8 of 16); CPF_ZYZ3_M overrides.
 int zyz3_cut(const cpf_plan* plan) {
     const int K = plan->K;
-    int m = (3 * K + 2) / 4;
+    int m = cpf_zyz3_aot_cut(dense_rot_code(plan), K, plan->layer_ud);
+    if (m == 0) m = (9 * K + 10) / 20;
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }
@@ -787,24 +790,50 @@ cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, const std::vector<int>& ud) {
     }
     return spec;
 }
-bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) {
-    if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || a.loss_kind == 2) return false;
+// The kernel serves 3-qubit problems with 1..3 rotation letters, CP or CZ blocks, the |T|^2 losses and up to 30 blocks.  It is the
+// default while every workgroup of the launch is resident at once (34 KB of LDS per sample at 12 blocks: 4 per CU) and, for up to
+// 12 blocks, beyond that (config 2's shape at 2048 / 4096 samples: 11.6 / 23.0 ms against 12.3 / 24.3 on the gate-by-gate two-ended
+// kernel; config 3's shape at 4096 samples, 47 KB per sample, loses: 33.5 against 30.3).  A launch that selects another 3-qubit
+// family through its switches (CPF_SPLIT, CPF_PSTORE, ... - the A/B tools and the tests of those kernels) keeps that family.
+bool zyz3_serves(const cpf_plan* plan, int mode, int loss_kind) {          // what the kernel can run
+    if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || loss_kind == 2) return false;
     if (!cpf::zyz3_supported(plan->K, plan->n_rot) || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
-    if ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) return false;
-    const TuneVal e = tuning("CPF_ZYZ3");
-    return e && e[0] == '1';
+    return (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 <= plan->lds_per_cu;
 }
-bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    if (!zyz3_wanted(plan, a) || !plan->use_jit) return false;
-    const int M = zyz3_cut(plan);
-    const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(dense_rot_code(plan), plan->K, M, plan->layer_ud));
-    if (!k.fn) {
-        plan->jit_note = k.error;
-        if (k.error.find("forbidden") != std::string::npos) { *rc = fail(-30, "%s", k.error.c_str()); return true; }
-        return false;
-    }
+bool zyz3_by_samples(const cpf_plan* plan, int64_t S) {                    // where it is the default
+    const int64_t lds = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4, per_cu = (S + plan->num_cu - 1) / plan->num_cu;
+    return per_cu * lds <= plan->lds_per_cu || plan->K <= 12;
+}
+// second: the launch is past the K-specialised gate-by-gate kernels a cache may hold for saturated launches (try_split3_cached_k);
+// the kernel then still takes every shape but the one whose K-specialised two-ended kernel is built into the library (config 3's)
+bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, bool second) {
+    if (!zyz3_serves(plan, a.mode, a.loss_kind)) return false;
+    { const TuneVal e = tuning("CPF_ZYZ3"); if (e) return e[0] == '1'; }
+    for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_ZYZL", "CPF_JIT_K", "CPF_NO_AOT3"})
+        if (tuning(other)) return false;
+    if (zyz3_by_samples(plan, S)) return true;
+    const bool aot_k = plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && plan->K == 16 && plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2};
+    return second && !aot_k;
+}
+bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc, bool second = false) {
+    if (!zyz3_wanted(plan, a, S, second)) return false;
+    const int M = zyz3_cut(plan), rot = dense_rot_code(plan);
     const size_t lds = (size_t)cpf::zyz3_lds_floats(plan->K) * sizeof(float);
+    const TuneVal defs = tuning("CPF_ZYZ3_DEFS"), stamps = tuning("CPF_ZYZ3_STAMPS");
+    if (!defs && !stamps && cpf_zyz3_aot_cut(rot, plan->K, plan->layer_ud) == M) {
+        hipError_t e = hipSuccess;
+        cpf_zyz3_launch_aot(rot, plan->K, M, plan->layer_ud, a, S, lds, stream, &e);
+        plan->variant = "zyz3/aot waves=2 K cut=" + std::to_string(M);
+        *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
+        return true;
+    }
+    if (!plan->use_jit) return false;
+    // an optional kernel: where compiling is forbidden (CPF_JIT_FORBID_COMPILE=1) a shape that is not in a cache is a miss, and the
+    // gate-by-gate kernels follow
+    const char* forbid = getenv("CPF_JIT_FORBID_COMPILE");
+    const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(rot, plan->K, M, plan->layer_ud), forbid && forbid[0] == '1');
+    if (!k.fn) { if (k.error != "not cached") plan->jit_note = k.error; return false; }
     if (!module_lds_opt_in(k.fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the two-ended ZYZ-form kernel"; return false; }
     cpf::KArgs args = a;
     void* params[] = {&args};
@@ -898,6 +927,7 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     { const TuneVal e = tuning("CPF_ZYZL"); if (e && e[0] == '1' && plan->NQ == 3 && try_zyzl(plan, a, lw, S, stream, &rc)) return rc; }
     if (try_zyz3(plan, a, S, stream, &rc)) return rc;
     if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
+    if (try_zyz3(plan, a, S, stream, &rc, true)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_zyz(plan, a, S, stream, &rc)) return rc;
     if (try_dense(plan, a, S, stream, &rc)) return rc;
@@ -1267,6 +1297,21 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
         if (int rc = precompile_landed(code, spec.body)) return rc;
         report += "zyzl/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
         built++;
+    }
+    // 3 qubits: the two-ended ZYZ-form kernel where a launch of this many samples takes it by default (cpf_zyz3.h) - then nothing else
+    // is built for the shape: the gate-by-gate kernels that read the block count from the plan are part of the library
+    if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind) && zyz3_by_samples(&pl, num_samples)) {
+        const int M = zyz3_cut(&pl), rot = dense_rot_code(&pl);
+        if (cpf_zyz3_aot_cut(rot, pl.K, pl.layer_ud) != M) {
+            const cpf_jit::Spec spec = zyz3_jit_spec(rot, pl.K, M, pl.layer_ud);
+            const cpf_jit::Code code = cpf_jit::build(spec);
+            if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
+            if (int rc = precompile_landed(code, spec.body)) return rc;
+            report += "zyz3/jit(" + code.backend + ") waves=2 K cut=" + std::to_string(M) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+            built++;
+        }
+        if (buf && size) snprintf(buf, size, "%s", report.c_str());
+        return built;
     }
     for (const JitCandidate& c : jit_candidates(&pl, pl.P, loss_kind, lw, num_samples)) {
         const cpf_jit::Code code = cpf_jit::build(c.spec);

@@ -45,11 +45,12 @@ int main(int argc, char** argv) {
     setenv("CPF_JIT_FORBID_COMPILE", "1", 1);
     CHECK(cpf_jit_precompile(&pb, 64, buf, sizeof(buf)) < 0 && strstr(cpf_last_error(), "CPF_JIT_FORBID_COMPILE"));
     unsetenv("CPF_JIT_FORBID_COMPILE");
+    // (a 3-qubit shape whose samples are all resident at once: the two-ended ZYZ-form kernel, cpf_zyz3.h, and nothing else)
     int n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));
-    CHECK(n == 2 && strstr(buf, "[built]"));
+    CHECK(n == 1 && strstr(buf, "[built]") && strstr(buf, "zyz3/jit("));
     n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));
-    CHECK(n == 2 && strstr(buf, "[cached]") && !strstr(buf, "[built]"));
-    CHECK(cpf_jit_compiles() == 2);
+    CHECK(n == 1 && strstr(buf, "[cached]") && !strstr(buf, "[built]"));
+    CHECK(cpf_jit_compiles() == 1);
     // a cached hiprtc object (2x slower code) must not pin itself: built under CPF_JIT_BACKEND=hiprtc (as a profiled run
     // would), it is reused by a process that asks for hiprtc again, but a normal process with hipcc installed builds
     // the hipcc object instead of accepting it; and an unknown tuning switch is rejected
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
         CHECK(cpf_set_tuning("CPF_NOT_A_SWITCH", "1") < 0 && cpf_set_tuning("CPF_SPLIT", "0") == 0 && cpf_set_tuning("CPF_SPLIT", nullptr) == 0);
     }
     const int compiles_so_far = cpf_jit_compiles();
-    CHECK(compiles_so_far >= 4);
+    CHECK(compiles_so_far >= 3);
     // shapes served by ahead-of-time kernels need nothing: config 2 (3 qubits, chain) -> the JIT candidates exist but are never
     // reached at run time; config 5 (6 qubits on a ring) -> the dense-block instance is built ahead of time
     std::vector<int32_t> ring6; for (int b = 0; b < 60; b++) { ring6.push_back(b % 6); ring6.push_back((b % 6 + 1) % 6); }

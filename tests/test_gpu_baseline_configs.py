@@ -32,7 +32,9 @@ def _check_size_independent_properties(eng, init, out, S):
     lbest = np.take_along_axis(out['loss'], bi[:, None], 1)[:, 0]
     assert (out['passed'] == (lbest <= np.float32(1e-3))).all()                   # entry_loss flag
     re = _np(eng.loss_and_grad(out['params'][:, 1], with_grad=False))             # the stored best angles give the stored best regloss
-    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < (2e-6 if eng.num_qubits <= 4 else 1e-5)
+    # (another kernel and another factorisation of the same gates in float32: the generic kernel applies every rotation as cos / sin
+    # products, the optimisers run the ZYZ form of the blocks - 2.7e-6 at most over config 3's 512 samples of 16 blocks, signs mixed)
+    assert np.abs(re['regloss'] - out['regloss'][:, 1]).max() < (4e-6 if eng.num_qubits <= 4 else 1e-5)
     cp = out['params'][np.arange(S), bi][:, eng.cp_mask == 1] % np.float32(2 * np.pi)
     v = np.full(cp.shape, 2)
     v[cp < 0.2] = 0
@@ -66,14 +68,14 @@ def test_config3_toffoli_all_to_all_at_size():
     whole 4096 on one GPU, 2000 iterations; plus short-run oracle parity on the same target."""
     from cpflow_amd import workloads
     wl = workloads.CONFIGS['cfg3']
-    assert _short_run_parity(wl, S=5, T=14, tol=1e-5).startswith('split/aot waves=2')
+    assert _short_run_parity(wl, S=5, T=14, tol=1e-5) == 'zyz3/aot waves=2 K cut=7'
     eng = _engine(wl)
     stats = []
     for S, first in ((512, 1024), (4096, 0)):          # rank 2's block of the 8-GPU run; all samples on one GPU
         init = eng.initial_angles(wl.seed, 4096, first, S)
         out = _np(eng.optimize(init))
         # 512 samples = two per CU: both in one workgroup (even SIMD placement) with the cut for one wave per SIMD
-        assert eng.last_variant() == ('split/aot waves=2 states K pairs=2' if S == 512 else 'split/aot waves=2 K'), eng.last_variant()
+        assert eng.last_variant() == ('zyz3/aot waves=2 K cut=7' if S == 512 else 'split/aot waves=2 K'), eng.last_variant()
         _check_size_independent_properties(eng, init, out, S)
         ok = out['passed']
         assert ok.mean() > 0.5 and out['cz'][ok].min() <= 8          # Toffoli needs 6 CZ all-to-all; most starts converge
@@ -198,12 +200,15 @@ def _unbiased_against_float32_oracle(wl, S, cz_bins, same_cz_min, q_tol, pair_to
     return variant
 
 
-def test_config2_unbiased_against_float32_oracle():
-    """Config 2 at full size (1024 samples x 2000 iterations): quantiles within 2e-4 (a tenth of one CZ-equivalent of
-    penalty, r * 2 = 1.1e-3), >= 85 % of the commonly converged samples with the same CZ count."""
+@pytest.mark.parametrize('kernel', ['zyz3', 'split'])
+def test_config2_unbiased_against_float32_oracle(kernel, tune):
+    """Config 2 at full size (1024 samples x 2000 iterations) on the two-ended ZYZ-form kernel (cpf_zyz3.h, the default since
+    round 5) and on the gate-by-gate two-ended kernel it replaced, against ONE float32 oracle run: quantiles within 2e-4 (a tenth
+    of one CZ-equivalent of penalty, r * 2 = 1.1e-3), >= 85 % of the commonly converged samples with the same CZ count."""
     from cpflow_amd import workloads
     wl = workloads.CONFIGS['cfg2']
-    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(6, 14)), 0.85, 2e-4, 5e-5, 'split/aot')
+    tune.set('CPF_ZYZ3', '1' if kernel == 'zyz3' else '0')
+    _unbiased_against_float32_oracle(wl, wl.samples_per_gpu, list(range(6, 14)), 0.85, 2e-4, 5e-5, kernel + '/aot')
 
 
 @pytest.mark.parametrize('kernel', ['zyzl', 'layered'])

@@ -242,8 +242,10 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stderr
     import json
     lines = json.loads(r.stdout.strip().splitlines()[-1])
-    assert len(lines) == 2 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
-    assert lines[0].startswith('split/jit(hipcc) waves=2') and lines[1].startswith('layered/jit(hipcc) waves=1')
+    # a 3-qubit shape whose samples are all resident at once: the two-ended ZYZ-form kernel (cpf_zyz3.h), specialised on the block
+    # count and the cut, and nothing else (the gate-by-gate kernels that read the block count from the plan are in the library)
+    assert len(lines) == 1 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
+    assert lines[0].startswith('zyz3/jit(hipcc) waves=2 K cut=2 [built] cpf::zyz3_body<'), lines
     assert (os.stat(tmp_path / 'cache').st_mode & 0o077) == 0          # private directory
     r = run({'CPF_JIT_FORBID_COMPILE': '1'})                           # now served from the cache
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
@@ -269,13 +271,17 @@ def test_block_count_specialised_kernels_per_regime(tmp_path):
                 f"print(json.dumps(_precompile_one({chain3!r}, 'xyz', {K}, {S}, tuning={{'CPF_JIT_K': '1'}})))")
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CPF_JIT_CACHE=str(cache)), capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr
-        return re.sub(r'jit\(\w+\)', 'jit(hipcc)', json.loads(r.stdout.strip().splitlines()[-1])[0].replace('[built]', '[cached]'))
-    assert kernels(14, 100).startswith(f'split/jit(hipcc) waves=2 states K lone [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (2 << 16)}, 0, 1, 1, 2>')
-    assert kernels(14, 512).startswith(f'split/jit(hipcc) waves=2 states K pairs=2 [cached] cpf::split_body<8451, 1, {2 + 4 * 14 + (3 << 16)}, 0, 1, 1, 2>')
-    assert kernels(14, 700).startswith(f'split/jit(hipcc) waves=2 states K [cached] cpf::split_body<8451, 1, {2 + 4 * 14}, 0, 1, 1, 2>')
+        lines = json.loads(r.stdout.strip().splitlines()[-1])
+        return re.sub(r'jit\(\w+\)', 'jit(hipcc)', lines[0].replace('[built]', '[cached]')) if lines else ''
+    # round 5: while every sample of the launch is resident at once (and beyond that up to 12 blocks) the shape runs on the two-ended
+    # ZYZ-form kernel, specialised on the block count and the cut; the gate-by-gate two-ended kernel keeps the saturated launches
+    assert kernels(14, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 0, 1, 1, 2>')
+    assert kernels(14, 512).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 0, 1, 1, 2>')
+    assert kernels(14, 700).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached]')
+    assert kernels(12, 8192).startswith('zyz3/jit(hipcc) waves=2 K cut=5 [cached] cpf::zyz3_body<8451, 12, 5, 0, 1, 1, 2>') or kernels(12, 8192) == ''   # config 2's shape: in the library
     assert kernels(14, 8192).startswith(f'split/jit(hipcc) waves=2 K [cached] cpf::split_body<8451, 1, {1 + 4 * 14}, 0, 1, 1, 2>')
-    assert kernels(20, 100).startswith('split/jit(hipcc) waves=2 states K lone [cached]')
-    assert kernels(24, 100).startswith('split/jit(hipcc) waves=2 states K lone [cached]')   # 77 KB of LDS per sample: opted in at the launch
+    assert kernels(20, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=9 [cached]')
+    assert kernels(24, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=11 [cached]')         # 63 KB of LDS per sample
     from cpflow_amd.build import precompile_shapes
     ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
     assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 400, 700, 2048, 8192}
