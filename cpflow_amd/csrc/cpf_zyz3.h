@@ -112,6 +112,9 @@ __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp
 #ifndef CPF_Z3_MFMA
 #define CPF_Z3_MFMA 1            // A/B: 0 = six DPP stages + v_readlane (cpf_device.h wave_sum2)
 #endif
+#ifndef CPF_Z3_PRIO
+#define CPF_Z3_PRIO 1            // issue priority of wave B in launches whose workgroups are all resident (zyz3_body; 0 = never raised)
+#endif
 #ifndef CPF_Z3_STAGGER
 #define CPF_Z3_STAGGER 0         // units of 512 clocks by which every other sample starts late (zyz3_body)
 #endif
@@ -141,9 +144,26 @@ __device__ __forceinline__ void wave_sum3(float& x, float& y, float& z) {
     z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 63));
 }
 
+// per-half sums of three values (two samples share the owner wave, lanes 0 .. 31 and 32 .. 63): lane l receives the sums over its half
+__device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upper) {
+    x += dppz<0xB1>(x);  y += dppz<0xB1>(y);  z += dppz<0xB1>(z);
+    x += dppz<0x4E>(x);  y += dppz<0x4E>(y);  z += dppz<0x4E>(z);
+    x += dppz<0x124>(x); y += dppz<0x124>(y); z += dppz<0x124>(z);
+    x += dppz<0x128>(x); y += dppz<0x128>(y); z += dppz<0x128>(z);
+    x += dpp<0x142, 0xA, 0xF>(0.f, x); y += dpp<0x142, 0xA, 0xF>(0.f, y); z += dpp<0x142, 0xA, 0xF>(0.f, z);       // lanes 31 / 63: the halves' totals
+    const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31)), x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 31)), y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));
+    const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 31)), z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 63));
+    x = upper ? x1 : x0; y = upper ? y1 : y0; z = upper ? z1 : z0;
+}
+
 // ROT: rotation string and entangler (cpf_blocks.h rot_pack / rot_with_ent); KC: blocks; MC: blocks of wave A (1 .. KC-1);
-// UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20)
-template <int ROT, int KC, int MC, int... UD>
+// PAIRS: samples per workgroup (1 or 2); UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20).
+// PAIRS = 2 (2 K + 3 <= 32 items): four waves, two samples, each with its own copy of the LDS map - and ONE owner: wave B of the
+// first sample owns the angles of both (lanes 0 .. 31 the first sample's items, 32 .. 63 the second's).  The owner phases are
+// instruction streams of ~400 vector instructions per step whatever the number of busy lanes, and a step is bound by the instructions
+// issued: sharing them between two samples takes a fifth off the step.  The second sample's wave B only sweeps.
+template <int ROT, int KC, int MC, int PAIRS, int... UD>
 __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     using L = Lay<3, 0>;
     using PL = PairList<UD...>;
@@ -155,12 +175,17 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     constexpr int NRA = (RA + 63) / 64, NRB = (ROWS - RA + 63) / 64;
     static_assert(LL > 0 && NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     static_assert(M >= 1 && M < K && NITEM <= 64, "both waves sweep at least one block; one owner lane per item");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = (int)threadIdx.x & 127, lane = tid & 63;
+    static_assert(PAIRS == 1 || (PAIRS == 2 && NITEM <= 32), "two samples per workgroup: the items of each in half a wave");
+    extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+    const int tid = (int)threadIdx.x & 127, lane = tid & 63;     // thread of its wave pair
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = PAIRS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7) : 0;
+    float* smem = smem_wg + pair * Lds::TOTAL;                   // every sample has its own copy of the map
     const int P = NS + NBP * K;
     if (a.P != P) return;                                    // host error: plan and specialisation disagree
-    const int64_t s_idx = blockIdx.x;
+    // an odd batch: the last workgroup's second pair runs a copy of the last sample (it must meet the same barriers) and writes nothing
+    const int64_t s_raw = (int64_t)blockIdx.x * PAIRS + pair;
+    const int64_t s_idx = (PAIRS == 1 || s_raw < a.nsamples) ? s_raw : (int64_t)a.nsamples - 1;
 
     // ---- sweep constants of this lane
     bool lb[3]; float sg[3];
@@ -301,7 +326,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             CPF_STAMP(6)
         }
 #ifdef CPF_STAMPS
-        if (s_idx == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
+        if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
 #endif
         return;
     }
@@ -310,9 +335,23 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // wave B: blocks M .. K-1, and the owner of every angle: lane w < 2 K owns side w (block w >> 1, side w & 1), lanes 2 K .. 2 K + 2
     // the surface gates of the three qubits
     // =========================================================================================================================
-    const float* init = a.init + s_idx * P;
-    const uint8_t* frozen = a.frozen ? a.frozen + s_idx * P : nullptr;
-    float* out_best = a.out_params + (s_idx * 2 + 1) * P;
+#if CPF_Z3_PRIO
+    // wave B's instruction stream is the critical path of every step: while every workgroup of the launch is resident (a.prio, set by
+    // the host) it gets the higher issue priority on the SIMD it shares with a wave A (config 2: 5.38 -> 5.16 ms; in a launch of
+    // several rounds of workgroups the priority starves the other waves: 2048 samples 11.6 -> 14.8 ms)
+    if (a.prio) __builtin_amdgcn_s_setprio(CPF_Z3_PRIO);
+#endif
+    // the owner wave and, in it, the sample and the item of this lane
+    const bool owner_wave = pair == 0;
+    const bool upper = PAIRS > 1 && lane >= 32;
+    const int il = PAIRS > 1 ? (lane & 31) : lane, lane0 = lane - il;
+    float* osmem = smem_wg + (upper ? Lds::TOTAL : 0);
+    const int64_t os_raw = (int64_t)blockIdx.x * PAIRS + (upper ? 1 : 0);
+    const bool ovs = PAIRS == 1 || os_raw < a.nsamples;
+    const int64_t os_idx = ovs ? os_raw : (int64_t)a.nsamples - 1;
+    const float* init = a.init + os_idx * P;
+    const uint8_t* frozen = a.frozen ? a.frozen + os_idx * P : nullptr;
+    float* out_best = a.out_params + (os_idx * 2 + 1) * P;
     const float2 vt_ = a.target[row * 8 + col];
     const f2 vt = {vt_.x, vt_.y};
     // static structure: qubit of side w; every side on a qubit as a bit mask
@@ -326,21 +365,21 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     };
     int lastside[3] = {-1, -1, -1};
     for (int w = 0; w < 2 * K; w++) lastside[qubit_of(w)] = w;
-    const bool is_side = lane < 2 * K, is_qubit = lane >= 2 * K && lane < NITEM;
-    const int ib = lane >> 1, iside = lane & 1, iq = lane - 2 * K;
+    const bool is_side = owner_wave && il < 2 * K, is_qubit = owner_wave && il >= 2 * K && il < NITEM;
+    const int ib = il >> 1, iside = il & 1, iq = il - 2 * K;
     int prev = -1, prev_dn = -1;                             // previous side on the side's qubit (even lanes: also of the block's dn side)
     unsigned long long later = 0;                            // sides: later sides on the qubit; qubits: every side on it
     int pj[4] = {-1, -1, -1, -1};
     if (is_side) {
-        const int q = qubit_of(lane);
-        for (int w = lane - 1; w >= 0; w--) if (qubit_of(w) == q) { prev = w; break; }
-        for (int w = lane + 1; w < 2 * K; w++) if (qubit_of(w) == q) later |= 1ull << w;
-        if (iside == 0) { const int qd = qubit_of(lane + 1); for (int w = lane - 1; w >= 0; w--) if (qubit_of(w) == qd) { prev_dn = w; break; } }
+        const int q = qubit_of(il);
+        for (int w = il - 1; w >= 0; w--) if (qubit_of(w) == q) { prev = w; break; }
+        for (int w = il + 1; w < 2 * K; w++) if (qubit_of(w) == q) later |= 1ull << (lane0 + w);          // bit = the lane that owns the side
+        if (iside == 0) { const int qd = qubit_of(il + 1); for (int w = il - 1; w >= 0; w--) if (qubit_of(w) == qd) { prev_dn = w; break; } }
 #pragma unroll
         for (int k = 0; k < NR; k++) pj[k] = NS + NBP * ib + 2 * k + iside;
         if (ENT == 0 && iside == 0) pj[3] = NS + NBP * ib + 2 * NR;
     } else if (is_qubit) {
-        for (int w = 0; w < 2 * K; w++) if (qubit_of(w) == iq) later |= 1ull << w;
+        for (int w = 0; w < 2 * K; w++) if (qubit_of(w) == iq) later |= 1ull << (lane0 + w);
         pj[0] = 3 * iq; pj[1] = 3 * iq + 1; pj[2] = 3 * iq + 2;
     }
     f2 th01, th23, mm01 = {0.f, 0.f}, mm23 = {0.f, 0.f}, vv01 = {0.f, 0.f}, vv23 = {0.f, 0.f};
@@ -353,8 +392,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             if (pj[k] >= 0) {
                 t0[k] = init[pj[k]];
                 nl[k] = (frozen && frozen[pj[k]]) ? 0.f : -a.lr;
-                a.out_params[(s_idx * 2) * P + pj[k]] = t0[k];
-                out_best[pj[k]] = t0[k];
+                if (ovs) { a.out_params[(os_idx * 2) * P + pj[k]] = t0[k]; out_best[pj[k]] = t0[k]; }
             }
         }
         th01 = f2{t0[0], t0[1]}; th23 = f2{t0[2], t0[3]}; nlr01 = f2{nl[0], nl[1]}; nlr23 = f2{nl[2], nl[3]};
@@ -370,8 +408,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         rowP = Lds::row_blk(ib) + 3 * iside;
         row_s11 = ib == 0 ? 9 : Lds::row_blk(ib - 1) + 6;
         auto pz_row = [&](int pw, int w) { return pw >= 0 ? Lds::row_blk(pw >> 1) + 3 * (pw & 1) + 2 : 3 * qubit_of(w) + 2; };   // Pz of the previous side, or of the surface state
-        row_pzu = pz_row(prev, lane);
-        row_pzd = iside == 0 ? pz_row(prev_dn, lane + 1) : 0;
+        row_pzu = pz_row(prev, il);
+        row_pzd = iside == 0 ? pz_row(prev_dn, il + 1) : 0;
     } else if (is_qubit) rowP = 3 * iq;
     const int prev_off = Lds::REC1 + 4 * (prev >= 0 ? prev : 2 * K);
     // final left factors: the last side on each row qubit, read at the start of every step
@@ -401,6 +439,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #endif
     for (int it = 0; it < iters; it++) {
         // ================= owner: Adam closes the previous step; (cos, sin); sides, parities, e-pairs, tables, surface matrices
+        if (owner_wave) {
         if (it > 0) {
             // optax scale_by_adam (optimization.py:14-25): the same operations in the same order as the scalar form, per half
             const float2 bc = const_load_f2(a.bias, it - 1);
@@ -426,7 +465,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }
         if (has_cp && a.use_reg) {
             float sl;
-            smem[Lds::PV + ib] = penalty_lds(smem, a.pen_kind, th23.y, sl);
+            osmem[Lds::PV + ib] = penalty_lds(osmem, a.pen_kind, th23.y, sl);
             psl = a.r * sl;
         }
         {
@@ -435,17 +474,17 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 c = cs[k][0]; sn = cs[k][1]; kind = 0;
             };
             sd = zyz::side_build<ROT & 0xFFFF>(rrec, NR, iside);
-            if (is_side) *reinterpret_cast<float4*>(smem + Lds::REC1 + 4 * lane) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
+            if (is_side) *reinterpret_cast<float4*>(osmem + Lds::REC1 + 4 * il) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
             const unsigned long long fbits = __builtin_amdgcn_ballot_w64(is_side && sd.f != 0);
             sd.m = __popcll(fbits & later) & 1;
             if (is_qubit) {                                  // the qubit's surface matrix with every flip on the qubit applied
                 float sm[8];
                 zyz::surface_matrix(sm, cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], sd.m);
-                *reinterpret_cast<float4*>(smem + Lds::SURFM + 8 * iq) = make_float4(sm[0], sm[1], sm[2], sm[3]);
-                *reinterpret_cast<float4*>(smem + Lds::SURFM + 8 * iq + 4) = make_float4(sm[4], sm[5], sm[6], sm[7]);
+                *reinterpret_cast<float4*>(osmem + Lds::SURFM + 8 * iq) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+                *reinterpret_cast<float4*>(osmem + Lds::SURFM + 8 * iq + 4) = make_float4(sm[4], sm[5], sm[6], sm[7]);
             }
             lds_fence();
-            const float4 pl = *reinterpret_cast<const float4*>(smem + prev_off);
+            const float4 pl = *reinterpret_cast<const float4*>(osmem + prev_off);
             const zyz::EPair e = zyz::side_epair(sd, true, zyz::c2(pl.x, pl.y), zyz::c2(pl.z, pl.w));      // "no previous side" reads the identity record
             // the block's other side is the neighbouring lane: exchange the e-pairs instead of a trip through LDS, then this lane
             // builds the two entries with a_up = iside (side 0: entries (0, 0), (0, 1); side 1: (1, 0), (1, 1))
@@ -468,10 +507,11 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             const float tus = iside ? tu : -tu;
             cacb = e.c | (pc << 1);
             if (is_side) {
-                float4* dst = reinterpret_cast<float4*>(smem + Lds::TAB + 16 * ib + 8 * iside);
+                float4* dst = reinterpret_cast<float4*>(osmem + Lds::TAB + 16 * ib + 8 * iside);
                 dst[0] = make_float4(d0.x, d0.y, tus, -td);
                 dst[1] = make_float4(d1.x, d1.y, tus, td);
             }
+        }
         }
         CPF_STAMP(0)                                  // owner / build
         barrier();
@@ -483,7 +523,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         f2 own[K - M + 1];
         float4 pvq[(K + 3) / 4];
 #pragma unroll
-        for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(smem + Lds::PV)[k];
+        for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(osmem + Lds::PV)[k];
         float2 lf[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) lf[q] = *reinterpret_cast<const float2*>(smem + lfin_off[q]);
@@ -516,35 +556,37 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         const f2 tt = z3_cmul_conj(x, psi_c);
         float tr = tt.x, ti = tt.y;
         z3_allsum(tr, ti, odd);
-        float pen_sum = 0.f;
-        if (a.use_reg) {
+        if (owner_wave) {
+            float otr = tr, oti = ti;                 // T of the sample this lane's item belongs to
+            if constexpr (PAIRS > 1) {                // the second sample's T: its wave pair forms it too, but not where the angles live
+                const f2* sp1 = reinterpret_cast<const f2*>(smem_wg + Lds::TOTAL + Lds::STATES) + lane;
+                const f2 t1 = z3_cmul_conj(sp1[64 * (M + 1)], sp1[64 * M]);
+                float tr1 = t1.x, ti1 = t1.y;
+                z3_allsum(tr1, ti1, odd);
+                otr = upper ? tr1 : tr; oti = upper ? ti1 : ti;
+            }
+            float pen_sum = 0.f;
+            if (a.use_reg) {
 #pragma unroll
-            for (int k = 0; k < (K + 3) / 4; k++) pen_sum += (pvq[k].x + pvq[k].y) + (pvq[k].z + pvq[k].w);
-        }
-        {
+                for (int k = 0; k < (K + 3) / 4; k++) pen_sum += (pvq[k].x + pvq[k].y) + (pvq[k].z + pvq[k].w);
+            }
             const float reg = a.use_reg ? a.r * pen_sum : 0.f;
-            const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
+            const float loss = 1.f - fmaf(otr, otr, oti * oti) * a.inv_dim2;
             const float regloss = loss + reg;
             bool improved = false;
             if (it == 0) { first = regloss; best = regloss; }
             else if (regloss < best) { best = regloss; improved = true; }
-#ifndef CPF_STAMPS
-            if (improved || a.hist_params) {
-                const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (pj[k] < 0) continue;
-                    if (improved) out_best[pj[k]] = t0[k];
-                    if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + pj[k]] = t0[k];
-                }
-            }
-            if (a.hist_loss && lane == 0) a.hist_loss[s_idx * a.T + it] = regloss;
-#else
-            if (improved) {
-                const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
+            const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
+            if (improved && ovs) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (pj[k] >= 0) out_best[pj[k]] = t0[k];
             }
+#ifndef CPF_STAMPS
+            if (a.hist_params && ovs) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.hist_params[(os_idx * a.T + it) * P + pj[k]] = t0[k];
+            }
+            if (a.hist_loss && il == 0 && ovs) a.hist_loss[os_idx * a.T + it] = regloss;
 #endif
         }
         if (a.T == 0) break;
@@ -581,8 +623,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         CPF_STAMP(6)
 
         // ================= chain rule, into the owners' registers
-        {
-            const float* tot = smem + Lds::TOT;
+        if (owner_wave) {
+            const float* tot = osmem + Lds::TOT;
             const float px = tot[rowP], py = tot[rowP + 1], pz = tot[rowP + 2];
             const float s11 = tot[row_s11], pzu = tot[row_pzu], pzd = tot[row_pzd];
             auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
@@ -602,36 +644,37 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         CPF_STAMP(7)
     }
 #ifdef CPF_STAMPS
-    if (s_idx == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 + k] = (float)stamp_sum[k];
+    if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 + k] = (float)stamp_sum[k];
 #endif
 
     // ---- epilogue (optimization.py:365-370, cp_utils.py:144-164): reg recompute, loss = regloss - reg, argmin, CZ count, entry-loss flag
-    {
+    if (owner_wave) {
         const int bi = (best < first) ? 1 : 0;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
             const int j = pj[3];
-            const float t0 = a.out_params[(s_idx * 2) * P + j], t1 = out_best[j];
+            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = out_best[j];
             float sl;
-            if (a.use_reg) { acc0 = penalty_lds(smem, a.pen_kind, t0, sl); acc1 = penalty_lds(smem, a.pen_kind, t1, sl); }
+            if (a.use_reg) { acc0 = penalty_lds(osmem, a.pen_kind, t0, sl); acc1 = penalty_lds(osmem, a.pen_kind, t1, sl); }
             acc2 = cz_value(bi ? t1 : t0, a.thr_cp);
         }
-        wave_sum3(acc0, acc1, acc2);
-        if (lane == 0) {
+        if constexpr (PAIRS > 1) half_sum3(acc0, acc1, acc2, upper);
+        else wave_sum3(acc0, acc1, acc2);
+        if (il == 0 && ovs) {
             const float reg0 = a.use_reg ? a.r * acc0 : 0.f, reg1 = a.use_reg ? a.r * acc1 : 0.f;
             const float l0 = first - reg0, l1 = best - reg1;
-            a.out_regloss[s_idx * 2 + 0] = first; a.out_regloss[s_idx * 2 + 1] = best;
-            a.out_reg[s_idx * 2 + 0] = reg0;      a.out_reg[s_idx * 2 + 1] = reg1;
-            a.out_loss[s_idx * 2 + 0] = l0;       a.out_loss[s_idx * 2 + 1] = l1;
-            a.out_cz[s_idx] = (int32_t)acc2;
-            a.out_pass[s_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
+            a.out_regloss[os_idx * 2 + 0] = first; a.out_regloss[os_idx * 2 + 1] = best;
+            a.out_reg[os_idx * 2 + 0] = reg0;      a.out_reg[os_idx * 2 + 1] = reg1;
+            a.out_loss[os_idx * 2 + 0] = l0;       a.out_loss[os_idx * 2 + 1] = l1;
+            a.out_cz[os_idx] = (int32_t)acc2;
+            a.out_pass[os_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
         }
     }
 }
 
-template <int ROT, int KC, int MC, int... UD>
-__global__ __launch_bounds__(128, 1) void k_cp_zyz3(const KArgs a) {
-    zyz3_body<ROT, KC, MC, UD...>(a);
+template <int ROT, int KC, int MC, int PAIRS, int... UD>
+__global__ __launch_bounds__(128 * PAIRS, 1) void k_cp_zyz3(const KArgs a) {
+    zyz3_body<ROT, KC, MC, PAIRS, UD...>(a);
 }
 
 }  // namespace cpf

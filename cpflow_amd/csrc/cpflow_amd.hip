@@ -765,18 +765,27 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
     return e == hipSuccess ? 0 : fail((int)e, "hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
 }
 
-// ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut and layer are compile-time constants of every instance.
-// The cut M (blocks swept by wave A; wave B also owns every angle): measured best near 0.45 K (config 2's shape, 1024 samples:
-// 5.36 / 5.48 / 5.62 / 6.19 ms for 5 / 6 / 7 / 8 of 12; config 3's share 5.82 / 5.76 / 6.22 for 6 / 7 / 8 of 16); CPF_ZYZ3_M overrides.
-int zyz3_cut(const cpf_plan* plan) {
+// ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut, samples per workgroup and layer are compile-time constants of
+// every instance.  Three launch regimes by samples per CU (same box, config 2's shape, ms for cuts 4 / 5 / 6 / 7 of 12 blocks):
+//   one (256 samples)      - / 4.72 / 4.55 / 4.62          two (512): 5.05 at 5, 5.26 at 6; with both samples in ONE workgroup (the
+//   hardware starts two-wave workgroups one SIMD apart, which books a SIMD twice at two per CU) 5.09 at 5, 4.84 at 6
+//   three, four (1024)     5.15 / 5.18 / 5.41 / 5.56       (config 3's share, 512 samples of 16 blocks: 5.85 / 5.72 / 6.16 at 6 / 7 / 8)
+// The cut M = blocks swept by wave A (wave B also owns every angle): CPF_ZYZ3_M overrides; CPF_ZYZ3_PAIRS the samples per workgroup.
+int64_t zyz3_per_cu(const cpf_plan* plan, int64_t S) { return (S + plan->num_cu - 1) / plan->num_cu; }
+int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
-    int m = cpf_zyz3_aot_cut(dense_rot_code(plan), K, plan->layer_ud);
-    if (m == 0) m = (9 * K + 10) / 20;
+    int m = (9 * K + (zyz3_per_cu(plan, S) <= 2 ? 12 : 10)) / 20;
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }
-cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, const std::vector<int>& ud) {
-    cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M}, ud), 128};
+int zyz3_pairs(const cpf_plan* plan, int64_t S) {
+    int pairs = (2 * plan->K + 3 <= 32 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;
+    { const TuneVal e = tuning("CPF_ZYZ3_PAIRS"); if (e) pairs = (e[0] == '2' && 2 * plan->K + 3 <= 32) ? 2 : 1; }
+    if ((int64_t)2 * cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) pairs = 1;
+    return pairs;
+}
+cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<int>& ud) {
+    cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M, pairs}, ud), 128 * pairs};
     { const TuneVal e = tuning("CPF_ZYZ3_STAMPS"); if (e && e[0] == '1') spec.flags = {"-DCPF_STAMPS"}; }      // diagnostics: per-phase cycle sums (tools/gpu.py stamps)
     {   // A/B builds: extra -D flags, separated by spaces
         const TuneVal e = tuning("CPF_ZYZ3_DEFS");
@@ -810,7 +819,7 @@ bool zyz3_by_samples(const cpf_plan* plan, int64_t S) {                    // wh
 bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, bool second) {
     if (!zyz3_serves(plan, a.mode, a.loss_kind)) return false;
     { const TuneVal e = tuning("CPF_ZYZ3"); if (e) return e[0] == '1'; }
-    for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_ZYZL", "CPF_JIT_K", "CPF_NO_AOT3"})
+    for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_ZYZL", "CPF_JIT_K", "CPF_NO_AOT3"})
         if (tuning(other)) return false;
     if (zyz3_by_samples(plan, S)) return true;
     const bool aot_k = plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && plan->K == 16 && plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2};
@@ -818,27 +827,34 @@ bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, bool seco
 }
 bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc, bool second = false) {
     if (!zyz3_wanted(plan, a, S, second)) return false;
-    const int M = zyz3_cut(plan), rot = dense_rot_code(plan);
-    const size_t lds = (size_t)cpf::zyz3_lds_floats(plan->K) * sizeof(float);
+    const int M = zyz3_cut(plan, S), rot = dense_rot_code(plan), pairs = zyz3_pairs(plan, S);
+    const size_t lds1 = (size_t)cpf::zyz3_lds_floats(plan->K) * sizeof(float), lds = lds1 * pairs;
+    const std::string tail = " waves=2 K cut=" + std::to_string(M) + (pairs == 2 ? " pairs=2" : "");
     const TuneVal defs = tuning("CPF_ZYZ3_DEFS"), stamps = tuning("CPF_ZYZ3_STAMPS");
-    if (!defs && !stamps && cpf_zyz3_aot_cut(rot, plan->K, plan->layer_ud) == M) {
+    if (!defs && !stamps) {
         hipError_t e = hipSuccess;
-        cpf_zyz3_launch_aot(rot, plan->K, M, plan->layer_ud, a, S, lds, stream, &e);
-        plan->variant = "zyz3/aot waves=2 K cut=" + std::to_string(M);
-        *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
-        return true;
+        cpf::KArgs args = a;
+        args.prio = zyz3_per_cu(plan, S) * (int64_t)lds1 <= plan->lds_per_cu;       // every workgroup resident: wave B gets the higher issue priority
+        { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
+        if (cpf_zyz3_launch_aot(rot, plan->K, M, pairs, plan->layer_ud, args, S, lds1, stream, &e)) {
+            plan->variant = "zyz3/aot" + tail;
+            *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
+            return true;
+        }
     }
     if (!plan->use_jit) return false;
     // an optional kernel: where compiling is forbidden (CPF_JIT_FORBID_COMPILE=1) a shape that is not in a cache is a miss, and the
     // gate-by-gate kernels follow
     const char* forbid = getenv("CPF_JIT_FORBID_COMPILE");
-    const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(rot, plan->K, M, plan->layer_ud), forbid && forbid[0] == '1');
+    const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(rot, plan->K, M, pairs, plan->layer_ud), forbid && forbid[0] == '1');
     if (!k.fn) { if (k.error != "not cached") plan->jit_note = k.error; return false; }
     if (!module_lds_opt_in(k.fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the two-ended ZYZ-form kernel"; return false; }
     cpf::KArgs args = a;
+    args.prio = zyz3_per_cu(plan, S) * (int64_t)lds1 <= plan->lds_per_cu;
+    { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
     void* params[] = {&args};
-    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)S, 1, 1, 128, 1, 1, (unsigned)lds, stream, params, nullptr);
-    plan->variant = "zyz3/jit(" + k.backend + ") waves=2 K cut=" + std::to_string(M);
+    const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)((S + pairs - 1) / pairs), 1, 1, 128 * pairs, 1, 1, (unsigned)lds, stream, params, nullptr);
+    plan->variant = "zyz3/jit(" + k.backend + ")" + tail;
     *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
     return true;
 }
@@ -1008,7 +1024,7 @@ const char* cpf_last_error(void) { return g_err; }
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
                                         "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
-                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {
@@ -1301,13 +1317,13 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     // 3 qubits: the two-ended ZYZ-form kernel where a launch of this many samples takes it by default (cpf_zyz3.h) - then nothing else
     // is built for the shape: the gate-by-gate kernels that read the block count from the plan are part of the library
     if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind) && zyz3_by_samples(&pl, num_samples)) {
-        const int M = zyz3_cut(&pl), rot = dense_rot_code(&pl);
-        if (cpf_zyz3_aot_cut(rot, pl.K, pl.layer_ud) != M) {
-            const cpf_jit::Spec spec = zyz3_jit_spec(rot, pl.K, M, pl.layer_ud);
+        const int M = zyz3_cut(&pl, num_samples), rot = dense_rot_code(&pl), pairs = zyz3_pairs(&pl, num_samples);
+        if (!cpf_zyz3_has_aot(rot, pl.K, M, pairs, pl.layer_ud)) {
+            const cpf_jit::Spec spec = zyz3_jit_spec(rot, pl.K, M, pairs, pl.layer_ud);
             const cpf_jit::Code code = cpf_jit::build(spec);
             if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
             if (int rc = precompile_landed(code, spec.body)) return rc;
-            report += "zyz3/jit(" + code.backend + ") waves=2 K cut=" + std::to_string(M) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
+            report += "zyz3/jit(" + code.backend + ") waves=2 K cut=" + std::to_string(M) + (pairs == 2 ? " pairs=2" : "") + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
             built++;
         }
         if (buf && size) snprintf(buf, size, "%s", report.c_str());
