@@ -624,16 +624,19 @@ def test_two_ended_kernel_agrees_with_one_wave_kernel(monkeypatch, tune):
     assert eng.last_variant().startswith('layered/')
 
 
-def test_issue_priority_does_not_change_results(monkeypatch, tune):
-    """The two-ended kernel raises the issue priority of its longer wave when the launch leaves SIMDs unsaturated
-    (cpf_split.h): a scheduling hint only - outputs are bit-identical with it on and off."""
+@pytest.mark.parametrize('family', ['zyz3', 'split'])
+def test_issue_priority_does_not_change_results(family, monkeypatch, tune):
+    """The two-ended kernels raise the issue priority of the wave whose instruction stream is the critical path of a step (cpf_zyz3.h:
+    wave B, the owner, while every workgroup is resident; cpf_split.h: the longer wave while SIMDs are unsaturated): a scheduling
+    hint only - outputs are bit-identical with it on and off."""
     ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
     res = {}
+    tune.set('CPF_ZYZ3', '1' if family == 'zyz3' else '0')
     for prio in ('0', '1'):
         tune.set('CPF_PRIO', prio)
         eng = _engine([[0, 1], [1, 2]], 12, ccz, 'xyz', num_gd_iterations=300)
         out = eng.optimize(eng.initial_angles(3, 200))
-        assert eng.last_variant().startswith('split/')
+        assert eng.last_variant().startswith(family + '/')
         res[prio] = {k: v.cpu().numpy() for k, v in out.items() if v is not None}
     for k in res['0']:
         assert np.array_equal(res['0'][k], res['1'][k]), k
