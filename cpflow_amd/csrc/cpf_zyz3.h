@@ -5,16 +5,18 @@
 //
 // One amplitude of the 8 x 8 unitary per lane (Lay<3, 0>: every row qubit on a DPP-reachable lane bit), two waves per sample:
 //   wave A   psi(s_b), b = -1 .. M-1: the (flipped) product state of the surface gates, then blocks 0 .. M-1 applied;
-//            lanes 0 .. 2 OWN the surface angles of the three qubits
+//            lanes 0 .. 2 OWN the surface angles of the three qubits, lanes 0 .. K-1 evaluate the penalty of the CP angles
 //   wave B   W(s_b), b = K-1 .. M-1: Vd = conj(dfin) V, then blocks K-1 .. M un-applied;
 //            lane w = 2 b + s OWNS the angles of side s of block b (side 0: the CP angle too)
 // with s_b the slice right after the two real stages of block b (cpf_zyz_math.h: what the sweeps hold there is the true state
 // up to pending flips and the left diagonals not yet merged).  A block is ONE complex multiply by the lane's merged phase and two
 // stages x += (+-t) x[partner] (two v_fmac_f32_dpp each): 6 vector instructions where the gate-by-gate sweep of cpf_split.h spends
-// 14 (four x / y rotations at 2 DPP + 1 packed, one merged diagonal).  Every state of the forward halves stays in LDS (K + 2 slots
-// of 512 B) and in the registers of the wave that made it, so the gradient halves move ONE matrix: wave A un-applies blocks
-// M-1 .. 0 from the cotangent w = f W with psi(s_b) at hand (the lane's own value kept from the forward half, the two partner
-// lanes' read back in one batch before the sweep); wave B applies blocks M .. K-1 to psi' = conj(f) psi with W(s_b) at hand.
+// 14 (four x / y rotations at 2 DPP + 1 packed, one merged diagonal).  Every state of the forward halves stays in the registers of
+// the wave that made it; LDS sees the two states at the cut only.  The gradient halves then move ONE matrix: wave A un-applies
+// blocks M-1 .. 0 from the cotangent w = f W with psi(s_b) at hand, wave B applies blocks M .. K-1 to psi' = conj(f) psi with
+// W(s_b) at hand - the lane's own value from its register, the two partner lanes' by four v_mov_b32_dpp from theirs (no longer the
+// sweep's live value, so the moves wait for nothing and fill the sweep's dependency stalls; reading them back from stored states
+// cost a 512-byte LDS write per block in the forward halves and two reads per block under the reduction: config 2 4.88 -> 4.76 ms).
 // At a slice the 7 generator sums of cpf_zyz_math.h come from three products per lane:
 //     conj(w) psi            -> Pz of the block's two qubits (signed by the lane's bits), the |11> sum of the NEXT block's pair
 //     conj(w) psi[partner]   -> Px (imaginary part), Py (real part, signed), once per qubit of the block
@@ -22,20 +24,30 @@
 //
 // The sums do not cross the lanes in the sweeps at all: every lane writes its 7 shares to LDS (one 272-byte row per sum: 64 lanes
 // + padding, conflict-free both ways), and each wave then adds ITS OWN rows with one lane per row - 16 ds_read_b128 and 33 packed
-// adds per 64 sums where the DPP reduce-scatter of cpf_blocks.h costs 28 issue slots per block inside the sweep.  With one state
-// per block instead of one per inner gate the rows fit next to the states (config 2: 25 KB + 7 KB per sample, four samples per CU).
+// adds per 64 sums where the DPP reduce-scatter of cpf_blocks.h costs 28 issue slots per block inside the sweep.
 //
-// A step is a dependent chain - angles -> tables -> sweeps -> sums -> gradients -> angles - so what is kept short is that chain:
+// A step is a dependent chain - angles -> tables -> sweeps -> sums -> gradients -> angles - and one wave's stream of dependent
+// instructions issues at 5 - 9 clocks each (tools/ubench/issue_cost.hip), so what counts is the LONGER of the two waves' streams
+// between barriers, not the instructions issued:
 //   * the side lanes build their block's table themselves: two sides of a block are neighbouring lanes, so a quad_perm exchange of
 //     the e-pairs replaces a trip through LDS, and each lane writes two of the four entries a sweep lane reads with one
 //     ds_read_b128: (d.re, d.im, signed t_up, signed t_dn).  The common phase of a block's entries is left in (no loss sees it);
 //   * the flip bits of all sides are ONE ballot (all sides sit in wave B), pending parities a popcount against a per-lane mask;
 //   * T = sum conj(W) psi over the 64 lanes is two v_mfma_f32_16x16x4_f32 against a register of ones (the matrix core as an
-//     adder tree: ~100 cycles where six DPP stages and two v_readlane take ~400), both waves, identical arithmetic;
+//     adder tree), both waves, identical arithmetic;
 //   * the penalty sum is K broadcast LDS reads in each wave (no cross-lane instruction);
-//   * the surface gates belong to wave A, whose owner phase (chain rule, Adam, sin / cos, the two variants S and F S of each
-//     surface matrix) runs while wave B does the same for the blocks; wave B only publishes the three flip parities.
+//   * everything that is not a block's side belongs to wave A, whose owner phase runs beside wave B's: the surface gates (chain
+//     rule, Adam, sin / cos, the two variants S and F S of each surface matrix - wave B only publishes the three flip parities) and
+//     the penalty of the CP angles, which wave B publishes right after its Adam update together with a step counter in LDS that
+//     wave A waits for (config 2, same box: 5.2 -> 4.9 ms once the cut moved from 5 to 4 blocks: wave A's share of the sweeps
+//     shrinks by what its owner phase grew).
 // Both waves form the loss with the same instructions and track the best iterate for the angles they own.
+//
+// No branch on the lane may sit next to the step loop's back edge: with `if (lane < 3) { store }` as the last statement of wave A's
+// loop the compiler split the loop by lanes (irreducible control flow repaired with a guard block), and the s_barrier at the loop's
+// top then ran once per group of lanes - the two waves lost step, silently (losses off by 1e-2 from the second step on, for some
+// cuts only).  Wave A's owner phase therefore sits at the top of the loop and stores without a branch (lanes that own nothing write
+// to rows of shares that are dead at that point).
 //
 // Requires: n = 3, 1..3 rotation letters (any), CP or CZ blocks, loss kinds with a linear cotangent (HST, state preparation),
 // 2 K <= 64 sides, K and the layer compile-time constants (instances: ahead of time for configs 2 / 3, cpf_jit.h otherwise).
@@ -50,10 +62,10 @@ constexpr int ZYZ3_ROW = 68;                     // floats per row of shares: 64
 // floats of LDS per sample of an instance with K blocks (Zyz3Lds<K>::TOTAL)
 __host__ __device__ constexpr int zyz3_lds_floats(int K) {
     const int rows = 10 + 7 * K;
-    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 24, states = (tot + rows + 3) & ~3;
-    return states + 128 * (K + 2) + rows * ZYZ3_ROW;
+    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 4, states = (tot + rows + 3) & ~3;
+    return states + 128 * 2 + rows * ZYZ3_ROW;
 }
-__host__ __device__ constexpr bool zyz3_supported(int K, int n_rot) { return K >= 2 && 2 * K + 3 <= 64 && n_rot >= 1 && n_rot <= 3; }
+__host__ __device__ constexpr bool zyz3_supported(int K, int n_rot) { return K >= 2 && 2 * K <= 64 && n_rot >= 1 && n_rot <= 3; }
 
 template <int K>
 struct Zyz3Lds {                                  // float offsets, per sample; [0, 28) = penalty table
@@ -61,11 +73,14 @@ struct Zyz3Lds {                                  // float offsets, per sample; 
     static constexpr int ROWS = 10 + 7 * K;       // 9 surface sums, S11 of block 0, then 7 per block (Px Py Pz up, Px Py Pz dn, S11 of the next block)
     static constexpr int REC1 = PEN_FLOATS;       // (2 K + 1) x {l0, l1}: left factors of a side; the last entry is the identity ("no previous side")
     static constexpr int PV = REC1 + 8 * K + 4;   // K penalty values (padded to a multiple of 4)
-    static constexpr int TAB = PV + up4(K);       // K x 4 entries x {d.re, d.im, t_up signed, t_dn signed}
-    static constexpr int SURFM = TAB + 16 * K;    // 3 x 2x2 complex: the flipped surface matrices
-    static constexpr int TOT = SURFM + 24;        // ROWS row totals
-    static constexpr int STATES = up4(TOT + ROWS);           // (K + 2) x 64 x (re, im)
-    static constexpr int PART = STATES + 128 * (K + 2);      // ROWS x ZYZ3_ROW
+    static constexpr int PTH = PV + up4(K);       // the K CP angles (wave B -> wave A, which evaluates the penalty)
+    static constexpr int PSL = PTH + up4(K);      // r x the penalty's slope at each of them (wave A -> wave B's next Adam step)
+    static constexpr int TAB = PSL + up4(K);      // K x 4 entries x {d.re, d.im, t_up signed, t_dn signed}
+    static constexpr int SURFM = TAB + 16 * K;    // 3 x {S, F S} x 2x2 complex: both variants of each surface matrix
+    static constexpr int MSF = SURFM + 48;        // the three flip parities (floats 0 / 1), one spare
+    static constexpr int TOT = MSF + 4;           // ROWS row totals
+    static constexpr int STATES = up4(TOT + ROWS);           // 2 x 64 x (re, im): the two states at the cut, psi(s_{M-1}) and W(s_{M-1})
+    static constexpr int PART = STATES + 128 * 2;            // ROWS x ZYZ3_ROW
     static constexpr int TOTAL = PART + ROWS * ZYZ3_ROW;
     static constexpr int row_blk(int b) { return 10 + 7 * b; }
     static_assert(TOTAL == zyz3_lds_floats(K), "the host's formula");
@@ -101,6 +116,12 @@ __device__ __forceinline__ void z3_stage(f2& x, float t) {
     else { CPF_Z3_STAGE("row_ror:8") }
 }
 #undef CPF_Z3_STAGE
+// the value held by the partner lane on row qubit Q (lane bits 0, 1, 3); every lane takes part
+template <int Q>
+__device__ __forceinline__ float z3_partner(float v) {
+    constexpr int CTRL = Q == 0 ? 0xB1 : (Q == 1 ? 0x4E : 0x128);       // quad_perm [1,0,3,2] / [2,3,0,1] / row_ror:8
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 // value of lane ^ 1 (quad_perm [1,0,3,2]); every lane takes part
 __device__ __forceinline__ float z3_nb(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
@@ -114,9 +135,6 @@ __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp
 #endif
 #ifndef CPF_Z3_PRIO
 #define CPF_Z3_PRIO 1            // issue priority of wave B in launches whose workgroups are all resident (zyz3_body; 0 = never raised)
-#endif
-#ifndef CPF_Z3_STAGGER
-#define CPF_Z3_STAGGER 0         // units of 512 clocks by which every other sample starts late (zyz3_body)
 #endif
 typedef float z3_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void z3_allsum(float& re, float& im, bool odd) {
@@ -159,10 +177,11 @@ __device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upp
 
 // ROT: rotation string and entangler (cpf_blocks.h rot_pack / rot_with_ent); KC: blocks; MC: blocks of wave A (1 .. KC-1);
 // PAIRS: samples per workgroup (1 or 2); UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20).
-// PAIRS = 2 (2 K + 3 <= 32 items): four waves, two samples, each with its own copy of the LDS map - and ONE owner: wave B of the
-// first sample owns the angles of both (lanes 0 .. 31 the first sample's items, 32 .. 63 the second's).  The owner phases are
-// instruction streams of ~400 vector instructions per step whatever the number of busy lanes, and a step is bound by the instructions
-// issued: sharing them between two samples takes a fifth off the step.  The second sample's wave B only sweeps.
+// PAIRS = 2 (2 K <= 32 sides): four waves, two samples, each with its own copy of the LDS map - and ONE owner of the sides: wave B
+// of the first sample owns the block angles of both (lanes 0 .. 31 the first sample's sides, 32 .. 63 the second's).  The owner
+// phase is a stream of ~300 vector instructions per step whatever the number of busy lanes; at two samples per CU (each wave on a
+// SIMD of its own) sharing it pays (config 2's shape, 512 samples: 4.59 against 4.77 ms).  The second sample's wave B only sweeps;
+// each sample's wave A owns its own surface gates and penalty.
 template <int ROT, int KC, int MC, int PAIRS, int... UD>
 __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     using L = Lay<3, 0>;
@@ -170,12 +189,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     using Lds = Zyz3Lds<KC>;
     constexpr int LL = sizeof...(UD) / 2, K = KC, M = MC;
     constexpr int NR = rot_nr(ROT), ENT = rot_ent(ROT), NBP = 2 * NR + (ENT == 0 ? 1 : 0), NS = 9;
-    constexpr int NITEM = 2 * K + 3;
+    constexpr int NITEM = 2 * K;                             // owner lanes of wave B: the sides
     constexpr int ROWS = Lds::ROWS, RA = Lds::row_blk(M);     // rows [0, RA) are written and added by wave A, [RA, ROWS) by wave B
     constexpr int NRA = (RA + 63) / 64, NRB = (ROWS - RA + 63) / 64;
     static_assert(LL > 0 && NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     static_assert(M >= 1 && M < K && NITEM <= 64, "both waves sweep at least one block; one owner lane per item");
-    static_assert(PAIRS == 1 || (PAIRS == 2 && NITEM <= 32), "two samples per workgroup: the items of each in half a wave");
+    static_assert(PAIRS == 1 || (PAIRS == 2 && NITEM <= 32), "two samples per workgroup: the sides of each in half a wave");
     extern __shared__ __attribute__((aligned(16))) float smem_wg[];
     const int tid = (int)threadIdx.x & 127, lane = tid & 63;     // thread of its wave pair
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,15 +219,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         m11[J] = (lb[UP] && lb[DN]) ? 1.f : 0.f;
         sgp[J] = f2{sg[UP], sg[DN]};
     }, typename make_iseq<LL>::type{});
-    f2* sp = reinterpret_cast<f2*>(smem + Lds::STATES) + lane;             // slot s at sp[64 s]
-    const float* spx[3];                                                   // the same slot seen from the partner lane on qubit q (re at [0], im at [1])
-#pragma unroll
-    for (int q = 0; q < 3; q++) spx[q] = reinterpret_cast<const float*>(sp + ((lane ^ (1 << L::row_lane_bit(q))) - lane));
+    f2* sp = reinterpret_cast<f2*>(smem + Lds::STATES) + lane;             // sp[0]: wave A's state at the cut, sp[64]: wave B's
     float* part = smem + Lds::PART + lane;                                 // row r at part[ZYZ3_ROW r]
     const float* tab = smem + Lds::TAB;
     penalty_table_init(smem, a, tid);
     if (tid == 0) *reinterpret_cast<float4*>(smem + Lds::REC1 + 8 * K) = make_float4(1.f, 0.f, 1.f, 0.f);
-    if (tid < Lds::up4(K)) smem[Lds::PV + tid] = 0.f;
+    if (tid < 3 * Lds::up4(K)) smem[Lds::PV + tid] = 0.f;
 
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
     auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -232,69 +248,189 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
 #endif
+    // ---- the angles of an owner lane's item (four slots: a side's rotation letters and, slot 3, the CP angle; a qubit's three surface
+    // angles), their Adam state and (cos, sin): wave B's side lanes, wave A's qubit lanes
+    int pj[4] = {-1, -1, -1, -1};
+    f2 th01 = {0.f, 0.f}, th23 = {0.f, 0.f}, mm01 = {0.f, 0.f}, mm23 = {0.f, 0.f}, vv01 = {0.f, 0.f}, vv23 = {0.f, 0.f};
+    f2 g01 = {0.f, 0.f}, g23 = {0.f, 0.f}, nlr01 = {0.f, 0.f}, nlr23 = {0.f, 0.f};
+    float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
+    float best = 0.f, first = 0.f;
+    auto load_angles = [&](int64_t sample, bool live) __attribute__((always_inline)) {
+        float t0[4], nl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            t0[k] = 0.f; nl[k] = 0.f;
+            if (pj[k] >= 0) {
+                t0[k] = a.init[sample * P + pj[k]];
+                nl[k] = (a.frozen && a.frozen[sample * P + pj[k]]) ? 0.f : -a.lr;
+                if (live) { a.out_params[(sample * 2) * P + pj[k]] = t0[k]; a.out_params[(sample * 2 + 1) * P + pj[k]] = t0[k]; }
+            }
+        }
+        th01 = f2{t0[0], t0[1]}; th23 = f2{t0[2], t0[3]}; nlr01 = f2{nl[0], nl[1]}; nlr23 = f2{nl[2], nl[3]};
+    };
+    // Adam closes step `it - 1` (optax scale_by_adam, optimization.py:14-25: the same operations in the same order as the scalar form, per
+    // half), then (cos, sin) of the half angles (slot 3: a CP angle, the full angle)
+    auto adam_sincos = [&](int it) __attribute__((always_inline)) {
+        if (it > 0) {
+            const float2 bc = const_load_f2(a.bias, it - 1);
+            const f2 ibc = f2{__builtin_amdgcn_rcpf(bc.x), __builtin_amdgcn_rcpf(bc.y)};
+            const f2 m0 = pk_fma(splat(a.b1), mm01, splat(a.omb1) * g01), m1 = pk_fma(splat(a.b1), mm23, splat(a.omb1) * g23);
+            const f2 v0 = pk_fma(splat(a.b2), vv01, splat(a.omb2) * (g01 * g01)), v1 = pk_fma(splat(a.b2), vv23, splat(a.omb2) * (g23 * g23));
+            mm01 = m0; mm23 = m1; vv01 = v0; vv23 = v1;
+            const f2 h0 = v0 * splat(ibc.y), h1 = v1 * splat(ibc.y);
+            const f2 d0 = f2{__builtin_amdgcn_sqrtf(h0.x), __builtin_amdgcn_sqrtf(h0.y)} + splat(a.eps);
+            const f2 d1 = f2{__builtin_amdgcn_sqrtf(h1.x), __builtin_amdgcn_sqrtf(h1.y)} + splat(a.eps);
+            const f2 u0 = (m0 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)};
+            const f2 u1 = (m1 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+            th01 = pk_fma(nlr01, u0, th01);
+            th23 = pk_fma(nlr23, u1, th23);
+        }
+        f2 s01, c01, s23, c23;
+        fast_sincos2(th01 * splat(0.5f), s01, c01);
+        fast_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);
+        cs[0][0] = c01.x; cs[0][1] = s01.x; cs[1][0] = c01.y; cs[1][1] = s01.y;
+        cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
+    };
+    // loss and best-iterate tracking from T and the penalty values of the lane's sample (both waves: the same instructions on the same numbers)
+    auto track = [&](int it, float tr, float ti, const float4 (&pvq)[(K + 3) / 4], int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
+        float pen_sum = 0.f;
+        if (a.use_reg) {
+#pragma unroll
+            for (int k = 0; k < (K + 3) / 4; k++) pen_sum += (pvq[k].x + pvq[k].y) + (pvq[k].z + pvq[k].w);
+        }
+        const float reg = a.use_reg ? a.r * pen_sum : 0.f;
+        const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
+        const float regloss = loss + reg;
+        bool improved = false;
+        if (it == 0) { first = regloss; best = regloss; }
+        else if (regloss < best) { best = regloss; improved = true; }
+        const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
+        if (improved && live) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.out_params[(sample * 2 + 1) * P + pj[k]] = t0[k];
+        }
+#ifndef CPF_STAMPS
+        if (a.hist_params && live) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.hist_params[(sample * a.T + it) * P + pj[k]] = t0[k];
+        }
+        if (a.hist_loss && writes_loss && live) a.hist_loss[sample * a.T + it] = regloss;
+#endif
+    };
 
     if (wave == 0) {
         // =====================================================================================================================
-        // wave A: blocks 0 .. M-1.  No angles: it needs T only for the cotangent.
+        // wave A: blocks 0 .. M-1, the surface gates, the penalty
         // =====================================================================================================================
-        int surf_off[3];                                     // element [r_q][c_q] of the (flipped) surface matrix of qubit q
+        int surf_off[3];                                     // element [r_q][c_q] of S_q; of F S_q 8 floats further
 #pragma unroll
-        for (int q = 0; q < 3; q++) surf_off[q] = Lds::SURFM + 8 * q + 4 * (lb[q] ? 1 : 0) + 2 * ((col >> (2 - q)) & 1);
+        for (int q = 0; q < 3; q++) surf_off[q] = Lds::SURFM + 16 * q + 4 * (lb[q] ? 1 : 0) + 2 * ((col >> (2 - q)) & 1);
+        // Lanes 0 .. 2 own the surface gates Rz(t2) Rx(t1) Rz(t0) of the three qubits (main.py:122-124): chain rule, Adam, (cos, sin)
+        // and both variants of the matrix (S and F S: which one the sweeps take is wave B's flip parity of the step) - behind the last
+        // barrier of a step, while wave B does the same for the blocks.  Lanes 0 .. K-1 also evaluate the penalty of the CP angles
+        // (penalty.py:44-71) that wave B publishes: ~35 instructions that would otherwise sit in wave B's stream.
+        const bool live = PAIRS == 1 || s_raw < a.nsamples;
+        const bool is_qubit = lane < 3;
+        if (is_qubit) { pj[0] = 3 * lane; pj[1] = 3 * lane + 1; pj[2] = 3 * lane + 2; }
+        load_angles(s_idx, live);
+        float my_flip = 0.f;
+        // No branch on the lane here: every lane forms a matrix and stores it, the lanes that own no qubit into the rows of shares
+        // (dead between the last barrier of a step and the gradient halves of the next).  A divergent region next to the loop's back
+        // edge made the compiler split the loop by lanes - the barrier at its top then ran once per group of lanes.
+        float* const pub = smem + (is_qubit ? Lds::SURFM : Lds::PART) + 16 * lane;
+        static_assert(Lds::ROWS * ZYZ3_ROW >= 64 * 16, "scratch for the lanes without a qubit");
+        const unsigned flag_addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)(smem + Lds::MSF + 3);      // LDS byte address
+        float* const pen_dst = smem + (lane < K ? Lds::PV + lane : Lds::PART + 1024 + 2 * lane);
+        static_assert(Lds::ROWS * ZYZ3_ROW >= 1024 + 128 + (Lds::PSL - Lds::PV), "scratch for the lanes without a CP angle");
+        auto publish_surface = [&]() __attribute__((always_inline)) {
+            float sm[8];
+            zyz::surface_matrix(sm, cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], 0);
+            float4* dst = reinterpret_cast<float4*>(pub);
+            dst[0] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+            dst[1] = make_float4(sm[4], sm[5], sm[6], sm[7]);
+            dst[2] = make_float4(-sm[4], -sm[5], -sm[6], -sm[7]);            // F S: row 0 = -row 1, row 1 = row 0
+            dst[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+        };
         barrier();                                           // constant records of the set-up
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
         for (int it = 0; it < iters; it++) {
+            {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
+                const float* tot = smem + Lds::TOT + 3 * (is_qubit ? lane : 0);
+                float gs[3] = {0.f, 0.f, 0.f};
+                if (it > 0) zyz::chain_surface(gs, tot[0], tot[1], tot[2], my_flip != 0.f ? 1 : 0, cs[1][0], cs[1][1], cs[2][0], cs[2][1]);
+                g01 = f2{gs[0], gs[1]}; g23 = f2{gs[2], 0.f};
+                adam_sincos(it);
+                publish_surface();
+                if (ENT == 0 && a.use_reg) {
+                    // the penalty of CP angle `lane` (penalty.py:44-71): its value for the loss, its slope for wave B's next Adam step.
+                    // Wave B publishes the angles right after its Adam update and then a step counter; by the time the surface
+                    // matrices are out it has long done so (its chain rule and Adam come first), so the wait is a formality - and it
+                    // cannot deadlock: wave B's stores depend on nothing this wave does before the barrier below.
+                    float seen;
+                    do {
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(flag_addr) : "memory");
+                    } while (__builtin_amdgcn_readfirstlane(__float_as_int(seen)) != __float_as_int((float)(it + 1)));
+                    const float th_cp = smem[Lds::PTH + (lane < K ? lane : K - 1)];
+                    float sl;
+                    const float pv = penalty_lds(smem, a.pen_kind, th_cp, sl);
+                    pen_dst[0] = pv;                         // no branch on the lane here either (see publish_surface)
+                    pen_dst[Lds::PSL - Lds::PV] = a.r * sl;
+                }
+            }
             CPF_STAMP(0)
             barrier();                                       // tables and surface matrices of this step
             CPF_STAMP(1)
             float4 ent[M];
             f2 own[M + 1];
-            float2 fs[3];
+            float4 pvq[(K + 3) / 4];
+            const float4 msf = *reinterpret_cast<const float4*>(smem + Lds::MSF);
+            float2 fa[3], fb[3];
 #pragma unroll
-            for (int q = 0; q < 3; q++) fs[q] = *reinterpret_cast<const float2*>(smem + surf_off[q]);
+            for (int q = 0; q < 3; q++) { fa[q] = *reinterpret_cast<const float2*>(smem + surf_off[q]); fb[q] = *reinterpret_cast<const float2*>(smem + surf_off[q] + 8); }
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = decltype(bb)::value;
                 ent[B] = *reinterpret_cast<const float4*>(tab + 16 * B + kofs[B % LL]);
             }, typename make_iseq<M>::type{});
-            f2 x = z3_cmul(f2{fs[2].x, fs[2].y}, z3_cmul(f2{fs[1].x, fs[1].y}, f2{fs[0].x, fs[0].y}));
-            sp[0] = x; own[0] = x;
+            my_flip = lane == 0 ? msf.x : (lane == 1 ? msf.y : msf.z);
+            const f2 f0 = msf.x != 0.f ? f2{fb[0].x, fb[0].y} : f2{fa[0].x, fa[0].y};
+            const f2 f1 = msf.y != 0.f ? f2{fb[1].x, fb[1].y} : f2{fa[1].x, fa[1].y};
+            const f2 f2_ = msf.z != 0.f ? f2{fb[2].x, fb[2].y} : f2{fa[2].x, fa[2].y};
+            f2 x = z3_cmul(f2_, z3_cmul(f1, f0));
+            own[0] = x;
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = decltype(bb)::value, J = B % LL;
                 x = z3_cmul(f2{ent[B].x, ent[B].y}, x);
                 z3_stage<PL::v[2 * J]>(x, ent[B].z);
                 z3_stage<PL::v[2 * J + 1]>(x, ent[B].w);
-                sp[64 * (B + 1)] = x; own[B + 1] = x;
+                own[B + 1] = x;
             }, typename make_iseq<M>::type{});
+            sp[0] = x;                                       // psi(s_{M-1}): the only state the other wave reads
             CPF_STAMP(2)                                  // forward half
             barrier();
             CPF_STAMP(3)
-            // the partner lanes' states of every slice, one batch under the reduction: pre[b] = (re at the up partner, re at the dn
-            // partner), pim[b] likewise, so that the two qubits of a block share packed instructions
-            const f2 w_c = sp[64 * (M + 1)];
-            f2 pre[M], pim[M], ps[3];
-            static_for([&](auto bb) __attribute__((always_inline)) {
-                constexpr int B = decltype(bb)::value, J = B % LL;
-                const float* qu = spx[PL::v[2 * J]] + 128 * (B + 1);
-                const float* qd = spx[PL::v[2 * J + 1]] + 128 * (B + 1);
-                pre[B] = f2{qu[0], qd[0]}; pim[B] = f2{qu[1], qd[1]};
-            }, typename make_iseq<M>::type{});
+            const f2 w_c = sp[64];
 #pragma unroll
-            for (int q = 0; q < 3; q++) ps[q] = f2{spx[q][0], spx[q][1]};
+            for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(smem + Lds::PV)[k];
             const f2 tt = z3_cmul_conj(w_c, x);              // T = sum conj(W) psi at the cut
             float tr = tt.x, ti = tt.y;
             z3_allsum(tr, ti, odd);
+            f2 w = z3_cmul(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, w_c);       // the cotangent at the cut: f W, f = -T / N^2
+            track(it, tr, ti, pvq, s_idx, live, false);
             if (a.T == 0) break;
             if (it + 1 == iters) break;
             CPF_STAMP(4)                                  // loss
-            f2 w = z3_cmul(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, w_c);       // the cotangent at the cut: f W, f = -T / N^2
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = M - 1 - decltype(bb)::value, J = B % LL, JN = (B + 1) % LL;
                 constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::row_blk(B);
                 const f2 o = own[B + 1];
+                // the partner lanes' psi(s_B) on the block's two qubits, straight from their registers (the state is no longer the
+                // sweep's live value, so the four moves wait for nothing and fill the sweep's dependency stalls): (re up, re dn), (im up, im dn)
+                const f2 pre = {z3_partner<UP>(o.x), z3_partner<DN>(o.x)}, pim = {z3_partner<UP>(o.y), z3_partner<DN>(o.y)};
                 // Im / Re of conj(w) psi[partner] for both qubits at once; Im(conj(w) psi) at the lane
-                const f2 PX = pk_fma(splat(w.x), pim[B], -(splat(w.y) * pre[B]));
-                const f2 PY = pk_fma(splat(w.x), pre[B], splat(w.y) * pim[B]) * sgp[J];
+                const f2 PX = pk_fma(splat(w.x), pim, -(splat(w.y) * pre));
+                const f2 PY = pk_fma(splat(w.x), pre, splat(w.y) * pim) * sgp[J];
                 const float u = fmaf(w.x, o.y, -w.y * o.x);
                 const f2 PZ = sgp[J] * splat(-u);
                 part[ZYZ3_ROW * (R0 + 0)] = PX.x;
@@ -313,7 +449,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 const float u = fmaf(w.x, o.y, -w.y * o.x);
                 static_for([&](auto qq) __attribute__((always_inline)) {
                     constexpr int Q = decltype(qq)::value;
-                    const f2 zq = w * swp(ps[Q]), yq = w * ps[Q];
+                    const f2 psq = {z3_partner<Q>(o.x), z3_partner<Q>(o.y)};
+                    const f2 zq = w * swp(psq), yq = w * psq;
                     part[ZYZ3_ROW * (3 * Q + 0)] = zq.x - zq.y;
                     part[ZYZ3_ROW * (3 * Q + 1)] = sg[Q] * (yq.x + yq.y);
                     part[ZYZ3_ROW * (3 * Q + 2)] = -sg[Q] * u;
@@ -324,6 +461,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             CPF_STAMP(5)                                  // gradient half + row sums
             barrier();
             CPF_STAMP(6)
+            CPF_STAMP(7)
         }
 #ifdef CPF_STAMPS
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
@@ -332,13 +470,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     }
 
     // =========================================================================================================================
-    // wave B: blocks M .. K-1, and the owner of every angle: lane w < 2 K owns side w (block w >> 1, side w & 1), lanes 2 K .. 2 K + 2
-    // the surface gates of the three qubits
+    // wave B: blocks M .. K-1, and the owner of every block angle: lane w < 2 K owns side w (block w >> 1, side w & 1)
     // =========================================================================================================================
 #if CPF_Z3_PRIO
-    // wave B's instruction stream is the critical path of every step: while every workgroup of the launch is resident (a.prio, set by
-    // the host) it gets the higher issue priority on the SIMD it shares with a wave A (config 2: 5.38 -> 5.16 ms; in a launch of
-    // several rounds of workgroups the priority starves the other waves: 2048 samples 11.6 -> 14.8 ms)
+    // While every workgroup of the launch is resident (a.prio, set by the host) wave B gets the higher issue priority on the SIMD it
+    // shares with a wave A of another sample (config 2, cut 4: 5.35 -> 4.74 ms; raising wave A's in its gradient half on top: 4.92).
+    // In a launch of several rounds of workgroups the priority starves the other waves (2048 samples 11.6 -> 14.8 ms).
     if (a.prio) __builtin_amdgcn_s_setprio(CPF_Z3_PRIO);
 #endif
     // the owner wave and, in it, the sample and the item of this lane
@@ -349,9 +486,6 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     const int64_t os_raw = (int64_t)blockIdx.x * PAIRS + (upper ? 1 : 0);
     const bool ovs = PAIRS == 1 || os_raw < a.nsamples;
     const int64_t os_idx = ovs ? os_raw : (int64_t)a.nsamples - 1;
-    const float* init = a.init + os_idx * P;
-    const uint8_t* frozen = a.frozen ? a.frozen + os_idx * P : nullptr;
-    float* out_best = a.out_params + (os_idx * 2 + 1) * P;
     const float2 vt_ = a.target[row * 8 + col];
     const f2 vt = {vt_.x, vt_.y};
     // static structure: qubit of side w; every side on a qubit as a bit mask
@@ -363,13 +497,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }, typename make_iseq<LL>::type{});
         return r;
     };
-    int lastside[3] = {-1, -1, -1};
+    int lastside[3] = {-1, -1, -1}, firstside[3] = {-1, -1, -1};
+    for (int w = 2 * K - 1; w >= 0; w--) firstside[qubit_of(w)] = w;
     for (int w = 0; w < 2 * K; w++) lastside[qubit_of(w)] = w;
-    const bool is_side = owner_wave && il < 2 * K, is_qubit = owner_wave && il >= 2 * K && il < NITEM;
-    const int ib = il >> 1, iside = il & 1, iq = il - 2 * K;
+    const bool is_side = owner_wave && il < 2 * K;
+    const int ib = il >> 1, iside = il & 1;
     int prev = -1, prev_dn = -1;                             // previous side on the side's qubit (even lanes: also of the block's dn side)
-    unsigned long long later = 0;                            // sides: later sides on the qubit; qubits: every side on it
-    int pj[4] = {-1, -1, -1, -1};
+    unsigned long long later = 0;                            // later sides on the side's qubit
+    int first_q = -1;                                        // the qubit this side is the first one on (it publishes the qubit's flip parity)
     if (is_side) {
         const int q = qubit_of(il);
         for (int w = il - 1; w >= 0; w--) if (qubit_of(w) == q) { prev = w; break; }
@@ -378,27 +513,11 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #pragma unroll
         for (int k = 0; k < NR; k++) pj[k] = NS + NBP * ib + 2 * k + iside;
         if (ENT == 0 && iside == 0) pj[3] = NS + NBP * ib + 2 * NR;
-    } else if (is_qubit) {
-        for (int w = 0; w < 2 * K; w++) if (qubit_of(w) == iq) later |= 1ull << (lane0 + w);
-        pj[0] = 3 * iq; pj[1] = 3 * iq + 1; pj[2] = 3 * iq + 2;
-    }
-    f2 th01, th23, mm01 = {0.f, 0.f}, mm23 = {0.f, 0.f}, vv01 = {0.f, 0.f}, vv23 = {0.f, 0.f};
-    f2 g01 = {0.f, 0.f}, g23 = {0.f, 0.f}, nlr01, nlr23;
-    {
-        float t0[4], nl[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            t0[k] = 0.f; nl[k] = 0.f;
-            if (pj[k] >= 0) {
-                t0[k] = init[pj[k]];
-                nl[k] = (frozen && frozen[pj[k]]) ? 0.f : -a.lr;
-                if (ovs) { a.out_params[(os_idx * 2) * P + pj[k]] = t0[k]; out_best[pj[k]] = t0[k]; }
-            }
-        }
-        th01 = f2{t0[0], t0[1]}; th23 = f2{t0[2], t0[3]}; nlr01 = f2{nl[0], nl[1]}; nlr23 = f2{nl[2], nl[3]};
+        for (int q = 0; q < 3; q++) if (firstside[q] == il) first_q = q;
     }
+    load_angles(os_idx, ovs);
     const bool has_cp = ENT == 0 && is_side && iside == 0;
-    float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
     zyz::Side sd = zyz::Side{};
     int cacb = 0;                                            // even side lanes: where the entangler's phase sits
     float psl = 0.f;
@@ -410,29 +529,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         auto pz_row = [&](int pw, int w) { return pw >= 0 ? Lds::row_blk(pw >> 1) + 3 * (pw & 1) + 2 : 3 * qubit_of(w) + 2; };   // Pz of the previous side, or of the surface state
         row_pzu = pz_row(prev, il);
         row_pzd = iside == 0 ? pz_row(prev_dn, il + 1) : 0;
-    } else if (is_qubit) rowP = 3 * iq;
+    }
     const int prev_off = Lds::REC1 + 4 * (prev >= 0 ? prev : 2 * K);
     // final left factors: the last side on each row qubit, read at the start of every step
     int lfin_off[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) lfin_off[q] = Lds::REC1 + 4 * (lastside[q] >= 0 ? lastside[q] : 2 * K) + 2 * (lb[q] ? 1 : 0);
 
-    float best = 0.f, first = 0.f;
-#if CPF_Z3_STAGGER > 0
-    // Samples of a launch run in lock step (the same instruction streams), and a SIMD hosts wave A of one sample and wave B of
-    // another: while every wave B is in its owner phase every wave A idles, and the sweeps of both then compete for the same issue
-    // slots.  Half of the samples therefore start a fraction of a step late - by the SIMD wave B sits on, so that the two waves of
-    // a SIMD belong to samples of opposite phase (the hardware places the two waves of consecutive workgroups on SIMDs (0, 1),
-    // (1, 2), (2, 3), (3, 0)).  Wave A waits at the barrier below.
-    {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if ((hw >> 4) & 1) {
-#pragma unroll
-            for (int k = 0; k < CPF_Z3_STAGGER; k++) __builtin_amdgcn_s_sleep(8);          // 8 x 64 clocks each
-        }
-    }
-#endif
+    if (owner_wave && il < 3 && firstside[il] < 0) osmem[Lds::MSF + il] = 0.f;      // a qubit no block touches is never flipped
     barrier();                                               // penalty table, constant records: written by wave A's lanes
 #ifdef CPF_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -440,33 +544,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     for (int it = 0; it < iters; it++) {
         // ================= owner: Adam closes the previous step; (cos, sin); sides, parities, e-pairs, tables, surface matrices
         if (owner_wave) {
-        if (it > 0) {
-            // optax scale_by_adam (optimization.py:14-25): the same operations in the same order as the scalar form, per half
-            const float2 bc = const_load_f2(a.bias, it - 1);
-            const f2 ibc = f2{__builtin_amdgcn_rcpf(bc.x), __builtin_amdgcn_rcpf(bc.y)};
-            if (has_cp && a.use_reg) g23.y += psl;
-            const f2 m0 = pk_fma(splat(a.b1), mm01, splat(a.omb1) * g01), m1 = pk_fma(splat(a.b1), mm23, splat(a.omb1) * g23);
-            const f2 v0 = pk_fma(splat(a.b2), vv01, splat(a.omb2) * (g01 * g01)), v1 = pk_fma(splat(a.b2), vv23, splat(a.omb2) * (g23 * g23));
-            mm01 = m0; mm23 = m1; vv01 = v0; vv23 = v1;
-            const f2 h0 = v0 * splat(ibc.y), h1 = v1 * splat(ibc.y);
-            const f2 d0 = f2{__builtin_amdgcn_sqrtf(h0.x), __builtin_amdgcn_sqrtf(h0.y)} + splat(a.eps);
-            const f2 d1 = f2{__builtin_amdgcn_sqrtf(h1.x), __builtin_amdgcn_sqrtf(h1.y)} + splat(a.eps);
-            const f2 u0 = (m0 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)};
-            const f2 u1 = (m1 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
-            th01 = pk_fma(nlr01, u0, th01);
-            th23 = pk_fma(nlr23, u1, th23);
-        }
-        {
-            f2 s01, c01, s23, c23;
-            fast_sincos2(th01 * splat(0.5f), s01, c01);
-            fast_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);                 // slot 3 is a CP angle: the full angle
-            cs[0][0] = c01.x; cs[0][1] = s01.x; cs[1][0] = c01.y; cs[1][1] = s01.y;
-            cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
-        }
-        if (has_cp && a.use_reg) {
-            float sl;
-            osmem[Lds::PV + ib] = penalty_lds(osmem, a.pen_kind, th23.y, sl);
-            psl = a.r * sl;
+        if (it > 0 && has_cp && a.use_reg) g23.y += psl;
+        adam_sincos(it);
+        if (ENT == 0 && a.use_reg) {                          // wave A evaluates the penalty of the CP angles: the angles, then the step counter it waits for
+            if (has_cp) osmem[Lds::PTH + ib] = th23.y;
+            lds_fence();
+            if (il == 0) osmem[Lds::MSF + 3] = (float)(it + 1);
         }
         {
             auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
@@ -477,12 +560,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             if (is_side) *reinterpret_cast<float4*>(osmem + Lds::REC1 + 4 * il) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
             const unsigned long long fbits = __builtin_amdgcn_ballot_w64(is_side && sd.f != 0);
             sd.m = __popcll(fbits & later) & 1;
-            if (is_qubit) {                                  // the qubit's surface matrix with every flip on the qubit applied
-                float sm[8];
-                zyz::surface_matrix(sm, cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], sd.m);
-                *reinterpret_cast<float4*>(osmem + Lds::SURFM + 8 * iq) = make_float4(sm[0], sm[1], sm[2], sm[3]);
-                *reinterpret_cast<float4*>(osmem + Lds::SURFM + 8 * iq + 4) = make_float4(sm[4], sm[5], sm[6], sm[7]);
-            }
+            if (first_q >= 0) osmem[Lds::MSF + first_q] = (float)(sd.m ^ sd.f);      // every flip on the qubit: those later than its first side, and that side's own
             lds_fence();
             const float4 pl = *reinterpret_cast<const float4*>(osmem + prev_off);
             const zyz::EPair e = zyz::side_epair(sd, true, zyz::c2(pl.x, pl.y), zyz::c2(pl.z, pl.w));      // "no previous side" reads the identity record
@@ -522,8 +600,6 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         float4 ent[K - M];
         f2 own[K - M + 1];
         float4 pvq[(K + 3) / 4];
-#pragma unroll
-        for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(osmem + Lds::PV)[k];
         float2 lf[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) lf[q] = *reinterpret_cast<const float2*>(smem + lfin_off[q]);
@@ -532,27 +608,24 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             ent[B - M] = *reinterpret_cast<const float4*>(tab + 16 * B + kofs[B % LL]);
         }, typename make_iseq<K - M>::type{});
         f2 x = z3_cmul_conj(z3_cmul(f2{lf[2].x, lf[2].y}, z3_cmul(f2{lf[1].x, lf[1].y}, f2{lf[0].x, lf[0].y})), vt);
-        sp[64 * (K + 1)] = x; own[K - M] = x;
+        own[K - M] = x;
         static_for([&](auto bb) __attribute__((always_inline)) {
             constexpr int B = K - 1 - decltype(bb)::value, J = B % LL;
             z3_stage<PL::v[2 * J + 1], true>(x, ent[B - M].w);
             z3_stage<PL::v[2 * J], true>(x, ent[B - M].z);
             x = z3_cmul_conj(f2{ent[B - M].x, ent[B - M].y}, x);
-            sp[64 * (B + 1)] = x; own[B - M] = x;                            // W(s_{B-1})
+            own[B - M] = x;                                                  // W(s_{B-1})
         }, typename make_iseq<K - M>::type{});
+        sp[64] = x;                                   // W(s_{M-1}): the only state the other wave reads
         CPF_STAMP(2)                                  // forward half
         barrier();
         CPF_STAMP(3)
 
         // ================= loss: T = sum conj(W) psi at the cut (wave A forms the same T for its cotangent)
-        const f2 psi_c = sp[64 * M];
-        f2 pre[K - M], pim[K - M];
-        static_for([&](auto bb) __attribute__((always_inline)) {
-            constexpr int B = M + decltype(bb)::value, J = B % LL;
-            const float* qu = spx[PL::v[2 * J]] + 128 * (B + 2);
-            const float* qd = spx[PL::v[2 * J + 1]] + 128 * (B + 2);
-            pre[B - M] = f2{qu[0], qd[0]}; pim[B - M] = f2{qu[1], qd[1]};
-        }, typename make_iseq<K - M>::type{});
+        const f2 psi_c = sp[0];
+#pragma unroll
+        for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(osmem + Lds::PV)[k];
+        if (has_cp) psl = osmem[Lds::PSL + ib];
         const f2 tt = z3_cmul_conj(x, psi_c);
         float tr = tt.x, ti = tt.y;
         z3_allsum(tr, ti, odd);
@@ -560,34 +633,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             float otr = tr, oti = ti;                 // T of the sample this lane's item belongs to
             if constexpr (PAIRS > 1) {                // the second sample's T: its wave pair forms it too, but not where the angles live
                 const f2* sp1 = reinterpret_cast<const f2*>(smem_wg + Lds::TOTAL + Lds::STATES) + lane;
-                const f2 t1 = z3_cmul_conj(sp1[64 * (M + 1)], sp1[64 * M]);
+                const f2 t1 = z3_cmul_conj(sp1[64], sp1[0]);
                 float tr1 = t1.x, ti1 = t1.y;
                 z3_allsum(tr1, ti1, odd);
                 otr = upper ? tr1 : tr; oti = upper ? ti1 : ti;
             }
-            float pen_sum = 0.f;
-            if (a.use_reg) {
-#pragma unroll
-                for (int k = 0; k < (K + 3) / 4; k++) pen_sum += (pvq[k].x + pvq[k].y) + (pvq[k].z + pvq[k].w);
-            }
-            const float reg = a.use_reg ? a.r * pen_sum : 0.f;
-            const float loss = 1.f - fmaf(otr, otr, oti * oti) * a.inv_dim2;
-            const float regloss = loss + reg;
-            bool improved = false;
-            if (it == 0) { first = regloss; best = regloss; }
-            else if (regloss < best) { best = regloss; improved = true; }
-            const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
-            if (improved && ovs) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (pj[k] >= 0) out_best[pj[k]] = t0[k];
-            }
-#ifndef CPF_STAMPS
-            if (a.hist_params && ovs) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.hist_params[(os_idx * a.T + it) * P + pj[k]] = t0[k];
-            }
-            if (a.hist_loss && il == 0 && ovs) a.hist_loss[os_idx * a.T + it] = regloss;
-#endif
+            track(it, otr, oti, pvq, os_idx, ovs, il == 0);
         }
         if (a.T == 0) break;
         if (it + 1 == iters) break;                   // the last step's gradient would move the angles past the last evaluated iterate
@@ -603,9 +654,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 z3_stage<UP>(pp, ent[B - M].z);
                 z3_stage<DN>(pp, ent[B - M].w);
                 const f2 o = own[B - M + 1];                                      // W(s_B)
+                const f2 pre = {z3_partner<UP>(o.x), z3_partner<DN>(o.x)}, pim = {z3_partner<UP>(o.y), z3_partner<DN>(o.y)};      // W(s_B) at the partner lanes
                 // the roles swapped: Im / Re of conj(W[partner]) psi' (the sign of the y sums changes), Im(conj(W) psi') at the lane
-                const f2 PX = pk_fma(splat(pp.y), pre[B - M], -(splat(pp.x) * pim[B - M]));
-                const f2 PY = pk_fma(splat(pp.x), pre[B - M], splat(pp.y) * pim[B - M]) * -sgp[J];
+                const f2 PX = pk_fma(splat(pp.y), pre, -(splat(pp.x) * pim));
+                const f2 PY = pk_fma(splat(pp.x), pre, splat(pp.y) * pim) * -sgp[J];
                 const float u = fmaf(o.x, pp.y, -o.y * pp.x);
                 const f2 PZ = sgp[J] * splat(-u);
                 part[ZYZ3_ROW * (R0 + 0)] = PX.x;
@@ -634,11 +686,6 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             float gp[4] = {0.f, 0.f, 0.f, 0.f};
             zyz::chain_side<ROT & 0xFFFF>(gp, px, py, pz, sd, rrec, NR, iside);
             if (ENT == 0) gp[3] = zyz::chain_cp(s11, pzu, pzd, cacb, 1.f);
-            if (is_qubit) {
-                float gs[3];
-                zyz::chain_surface(gs, px, py, pz, sd.m, cs[1][0], cs[1][1], cs[2][0], cs[2][1]);
-                gp[0] = gs[0]; gp[1] = gs[1]; gp[2] = gs[2]; gp[3] = 0.f;
-            }
             g01 = f2{gp[0], gp[1]}; g23 = f2{gp[2], gp[3]};
         }
         CPF_STAMP(7)
@@ -653,7 +700,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
             const int j = pj[3];
-            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = out_best[j];
+            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = a.out_params[(os_idx * 2 + 1) * P + j];
             float sl;
             if (a.use_reg) { acc0 = penalty_lds(osmem, a.pen_kind, t0, sl); acc1 = penalty_lds(osmem, a.pen_kind, t1, sl); }
             acc2 = cz_value(bi ? t1 : t0, a.thr_cp);

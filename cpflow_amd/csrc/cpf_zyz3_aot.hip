@@ -5,15 +5,16 @@
 
 namespace {
 constexpr int XYZ = cpf::rot_pack(3, cpf::OP_RX, cpf::OP_RY, cpf::OP_RZ);
-// lds: bytes per sample; PAIRS samples share a workgroup
+// lds: bytes of dynamic LDS per workgroup (PAIRS samples share one; the host may ask for more than the kernel uses)
 template <int ROT, int K, int M, int PAIRS, int... UD>
 hipError_t run(const cpf::KArgs& a, long long S, size_t lds, hipStream_t stream) {
-    if (PAIRS * lds > 64 * 1024) {
+    if (lds < (size_t)PAIRS * cpf::zyz3_lds_floats(K) * sizeof(float)) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpf::k_cp_zyz3<ROT, K, M, PAIRS, UD...>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PAIRS * lds));
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((cpf::k_cp_zyz3<ROT, K, M, PAIRS, UD...>), dim3((unsigned)((S + PAIRS - 1) / PAIRS)), dim3(128 * PAIRS), PAIRS * lds, stream, a);
+    hipLaunchKernelGGL((cpf::k_cp_zyz3<ROT, K, M, PAIRS, UD...>), dim3((unsigned)((S + PAIRS - 1) / PAIRS)), dim3(128 * PAIRS), lds, stream, a);
     return hipGetLastError();
 }
 const std::vector<int> CHAIN3 = {0, 1, 1, 2}, CONN3 = {0, 1, 0, 2, 1, 2};
@@ -21,16 +22,17 @@ const std::vector<int> CHAIN3 = {0, 1, 1, 2}, CONN3 = {0, 1, 0, 2, 1, 2};
 
 bool cpf_zyz3_has_aot(int rot, int K, int M, int pairs, const std::vector<int>& ud) {
     if (rot != XYZ) return false;
-    if (K == 12 && ud == CHAIN3) return (M == 5 && pairs == 1) || (M == 6 && (pairs == 1 || pairs == 2));
-    if (K == 16 && ud == CONN3) return M == 7 && pairs == 1;
+    if (K == 12 && ud == CHAIN3) return ((M == 4 || M == 5) && pairs == 1) || (M == 6 && pairs == 2);
+    if (K == 16 && ud == CONN3) return (M == 6 || M == 7) && pairs == 1;
     return false;
 }
 
 int cpf_zyz3_launch_aot(int rot, int K, int M, int pairs, const std::vector<int>& ud, const cpf::KArgs& a, long long S, size_t lds, hipStream_t stream, hipError_t* err) {
     if (!cpf_zyz3_has_aot(rot, K, M, pairs, ud)) return 0;
-    if (K == 12 && M == 5) *err = run<XYZ, 12, 5, 1, 0, 1, 1, 2>(a, S, lds, stream);
-    else if (K == 12 && pairs == 1) *err = run<XYZ, 12, 6, 1, 0, 1, 1, 2>(a, S, lds, stream);
+    if (K == 12 && M == 4) *err = run<XYZ, 12, 4, 1, 0, 1, 1, 2>(a, S, lds, stream);
+    else if (K == 12 && M == 5) *err = run<XYZ, 12, 5, 1, 0, 1, 1, 2>(a, S, lds, stream);
     else if (K == 12) *err = run<XYZ, 12, 6, 2, 0, 1, 1, 2>(a, S, lds, stream);
+    else if (M == 6) *err = run<XYZ, 16, 6, 1, 0, 1, 0, 2, 1, 2>(a, S, lds, stream);
     else *err = run<XYZ, 16, 7, 1, 0, 1, 0, 2, 1, 2>(a, S, lds, stream);
     return 1;
 }

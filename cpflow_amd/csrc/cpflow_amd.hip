@@ -766,23 +766,43 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 }
 
 // ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut, samples per workgroup and layer are compile-time constants of
-// every instance.  Three launch regimes by samples per CU (same box, config 2's shape, ms for cuts 4 / 5 / 6 / 7 of 12 blocks):
-//   one (256 samples)      - / 4.72 / 4.55 / 4.62          two (512): 5.05 at 5, 5.26 at 6; with both samples in ONE workgroup (the
-//   hardware starts two-wave workgroups one SIMD apart, which books a SIMD twice at two per CU) 5.09 at 5, 4.84 at 6
-//   three, four (1024)     5.15 / 5.18 / 5.41 / 5.56       (config 3's share, 512 samples of 16 blocks: 5.85 / 5.72 / 6.16 at 6 / 7 / 8)
-// The cut M = blocks swept by wave A (wave B also owns every angle): CPF_ZYZ3_M overrides; CPF_ZYZ3_PAIRS the samples per workgroup.
+// every instance.  The cut M = blocks swept by wave A, which also owns the surface gates and the penalty; wave B owns the blocks'
+// angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named):
+//   one sample per CU      256 samples: 4.21 / 4.20 / 4.37 at 5 / 6 / 7; 100 samples of 14 blocks 4.41 / 4.46 at 6 / 7, of 24 blocks
+//                          5.93 / 5.97 at 11 / 12                                                      -> (K - 1) / 2
+//   two per CU             512: 4.67 / 4.69 / 4.91 at 3 / 4 / 5; with both samples in ONE workgroup (the hardware starts two-wave
+//                          workgroups one SIMD apart, which books a SIMD twice at two per CU) 4.56 / 4.40 at 5 / 6  -> K / 2, pairs
+//   up to four, resident   1024: 4.78 / 4.76 / 5.02 / 5.13 at 3 / 4 / 5 / 6; config 3's shape (16 blocks) 512: 5.48 / 5.46 / 5.54
+//                          at 5 / 6 / 7, 1024: 5.61 / 5.55 at 5 / 6; 1000 samples of 8 CZ blocks 4.00 / 4.01 at 2 / 3 -> 0.36 K
+//   more                   1280: 7.09 / 6.89 at 4 / 5; 2048: 12.41 / 12.18; 4096: 21.89 / 21.49; config 3's shape 4096: 27.7 /
+//                          26.7 at 6 / 7                                                               -> 0.43 K
+// CPF_ZYZ3_M overrides the cut, CPF_ZYZ3_PAIRS the samples per workgroup, CPF_ZYZ3_RES the workgroups resident per CU.
 int64_t zyz3_per_cu(const cpf_plan* plan, int64_t S) { return (S + plan->num_cu - 1) / plan->num_cu; }
+int64_t zyz3_max_resident(const cpf_plan* plan) { return std::min<int64_t>(16, plan->lds_per_cu / ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4)); }
+bool zyz3_all_resident(const cpf_plan* plan, int64_t S) { return zyz3_per_cu(plan, S) <= zyz3_max_resident(plan); }
+int zyz3_pairs(const cpf_plan* plan, int64_t S) {
+    int pairs = (2 * plan->K <= 32 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;
+    { const TuneVal e = tuning("CPF_ZYZ3_PAIRS"); if (e) pairs = (e[0] == '2' && 2 * plan->K <= 32) ? 2 : 1; }
+    if ((int64_t)2 * cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) pairs = 1;
+    return pairs;
+}
 int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
-    int m = (9 * K + (zyz3_per_cu(plan, S) <= 2 ? 12 : 10)) / 20;
+    const int64_t per_cu = zyz3_per_cu(plan, S);
+    int m = per_cu <= 1 ? (K - 1) / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : ((per_cu <= 4 && zyz3_all_resident(plan, S)) ? (36 * K + 50) / 100 : (43 * K + 50) / 100));
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }
-int zyz3_pairs(const cpf_plan* plan, int64_t S) {
-    int pairs = (2 * plan->K + 3 <= 32 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;
-    { const TuneVal e = tuning("CPF_ZYZ3_PAIRS"); if (e) pairs = (e[0] == '2' && 2 * plan->K + 3 <= 32) ? 2 : 1; }
-    if ((int64_t)2 * cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) pairs = 1;
-    return pairs;
+// Dynamic LDS per workgroup.  A launch of more workgroups than fit at once runs in rounds (every workgroup takes the same time), so
+// what is resident per CU is evened out over the rounds by asking for more LDS than the kernel needs: 2048 samples of config 2's
+// shape (8 per CU, 5 fit) run as 4 + 4 instead of 5 + 3.
+size_t zyz3_lds_request(const cpf_plan* plan, int64_t S, int pairs) {
+    const int64_t lds1 = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 * pairs, per_cu = (zyz3_per_cu(plan, S) + pairs - 1) / pairs;
+    const int64_t fit = std::max<int64_t>(1, std::min<int64_t>(16 / pairs, plan->lds_per_cu / lds1));
+    int64_t res = per_cu <= fit ? 0 : (per_cu + (per_cu + fit - 1) / fit - 1) / ((per_cu + fit - 1) / fit);
+    { const TuneVal e = tuning("CPF_ZYZ3_RES"); if (e) res = atoi(e.s.c_str()); }
+    if (res <= 0 || res >= fit) return (size_t)lds1;
+    return (size_t)std::max<int64_t>(lds1, (plan->lds_per_cu / res) & ~(int64_t)255);
 }
 cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<int>& ud) {
     cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M, pairs}, ud), 128 * pairs};
@@ -799,44 +819,36 @@ cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<
     }
     return spec;
 }
-// The kernel serves 3-qubit problems with 1..3 rotation letters, CP or CZ blocks, the |T|^2 losses and up to 30 blocks.  It is the
-// default while every workgroup of the launch is resident at once (34 KB of LDS per sample at 12 blocks: 4 per CU) and, for up to
-// 12 blocks, beyond that (config 2's shape at 2048 / 4096 samples: 11.6 / 23.0 ms against 12.3 / 24.3 on the gate-by-gate two-ended
-// kernel; config 3's shape at 4096 samples, 47 KB per sample, loses: 33.5 against 30.3).  A launch that selects another 3-qubit
-// family through its switches (CPF_SPLIT, CPF_PSTORE, ... - the A/B tools and the tests of those kernels) keeps that family.
+// The kernel serves 3-qubit problems with 1..3 rotation letters, CP or CZ blocks, the |T|^2 losses and up to 32 blocks, and is the
+// default for all of them (29 KB of LDS per sample at 12 blocks, 37 KB at 16: config 2's shape at 2048 / 4096 samples 11.2 / 21.5 ms
+// against 12.3 / 24.3 on the gate-by-gate two-ended kernel, config 3's at 1024 / 4096 samples 5.55 / 26.7 against 7.55 / 29.8).
+// A launch that selects another 3-qubit family through its switches (CPF_SPLIT, CPF_PSTORE, ... - the A/B tools and the tests of
+// those kernels) keeps that family.
 bool zyz3_serves(const cpf_plan* plan, int mode, int loss_kind) {          // what the kernel can run
     if (plan->force_generic || mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || loss_kind == 2) return false;
     if (!cpf::zyz3_supported(plan->K, plan->n_rot) || plan->entangler == CPF_ENTANGLER_CX) return false;
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     return (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 <= plan->lds_per_cu;
 }
-bool zyz3_by_samples(const cpf_plan* plan, int64_t S) {                    // where it is the default
-    const int64_t lds = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4, per_cu = (S + plan->num_cu - 1) / plan->num_cu;
-    return per_cu * lds <= plan->lds_per_cu || plan->K <= 12;
-}
-// second: the launch is past the K-specialised gate-by-gate kernels a cache may hold for saturated launches (try_split3_cached_k);
-// the kernel then still takes every shape but the one whose K-specialised two-ended kernel is built into the library (config 3's)
-bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, bool second) {
+bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) {
     if (!zyz3_serves(plan, a.mode, a.loss_kind)) return false;
     { const TuneVal e = tuning("CPF_ZYZ3"); if (e) return e[0] == '1'; }
     for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_ZYZL", "CPF_JIT_K", "CPF_NO_AOT3"})
         if (tuning(other)) return false;
-    if (zyz3_by_samples(plan, S)) return true;
-    const bool aot_k = plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && plan->K == 16 && plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2};
-    return second && !aot_k;
+    return true;
 }
-bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc, bool second = false) {
-    if (!zyz3_wanted(plan, a, S, second)) return false;
+bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
+    if (!zyz3_wanted(plan, a)) return false;
     const int M = zyz3_cut(plan, S), rot = dense_rot_code(plan), pairs = zyz3_pairs(plan, S);
-    const size_t lds1 = (size_t)cpf::zyz3_lds_floats(plan->K) * sizeof(float), lds = lds1 * pairs;
+    const size_t lds = zyz3_lds_request(plan, S, pairs);
     const std::string tail = " waves=2 K cut=" + std::to_string(M) + (pairs == 2 ? " pairs=2" : "");
     const TuneVal defs = tuning("CPF_ZYZ3_DEFS"), stamps = tuning("CPF_ZYZ3_STAMPS");
+    cpf::KArgs args = a;
+    args.prio = zyz3_all_resident(plan, S);                  // every workgroup resident: wave B gets the higher issue priority
+    { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
     if (!defs && !stamps) {
         hipError_t e = hipSuccess;
-        cpf::KArgs args = a;
-        args.prio = zyz3_per_cu(plan, S) * (int64_t)lds1 <= plan->lds_per_cu;       // every workgroup resident: wave B gets the higher issue priority
-        { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
-        if (cpf_zyz3_launch_aot(rot, plan->K, M, pairs, plan->layer_ud, args, S, lds1, stream, &e)) {
+        if (cpf_zyz3_launch_aot(rot, plan->K, M, pairs, plan->layer_ud, args, S, lds, stream, &e)) {
             plan->variant = "zyz3/aot" + tail;
             *rc = e == hipSuccess ? 0 : fail((int)e, "two-ended ZYZ-form kernel launch failed: %s", hipGetErrorString(e));
             return true;
@@ -849,9 +861,6 @@ bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream
     const cpf_jit::Kernel& k = cpf_jit::get(plan->device, zyz3_jit_spec(rot, plan->K, M, pairs, plan->layer_ud), forbid && forbid[0] == '1');
     if (!k.fn) { if (k.error != "not cached") plan->jit_note = k.error; return false; }
     if (!module_lds_opt_in(k.fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the two-ended ZYZ-form kernel"; return false; }
-    cpf::KArgs args = a;
-    args.prio = zyz3_per_cu(plan, S) * (int64_t)lds1 <= plan->lds_per_cu;
-    { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
     void* params[] = {&args};
     const hipError_t e = hipModuleLaunchKernel(k.fn, (unsigned)((S + pairs - 1) / pairs), 1, 1, 128 * pairs, 1, 1, (unsigned)lds, stream, params, nullptr);
     plan->variant = "zyz3/jit(" + k.backend + ")" + tail;
@@ -943,7 +952,6 @@ int launch(const cpf_plan* plan_c, const cpf::KArgs& a_in, int64_t S, hipStream_
     { const TuneVal e = tuning("CPF_ZYZL"); if (e && e[0] == '1' && plan->NQ == 3 && try_zyzl(plan, a, lw, S, stream, &rc)) return rc; }
     if (try_zyz3(plan, a, S, stream, &rc)) return rc;
     if (try_split3_cached_k(plan, a, S, stream, &rc)) return rc;
-    if (try_zyz3(plan, a, S, stream, &rc, true)) return rc;
     if (try_layered3_aot(plan, a, S, stream, &rc)) return rc;
     if (try_zyz(plan, a, S, stream, &rc)) return rc;
     if (try_dense(plan, a, S, stream, &rc)) return rc;
@@ -1024,7 +1032,7 @@ const char* cpf_last_error(void) { return g_err; }
 int32_t cpf_set_tuning(const char* name, const char* value) {
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
                                         "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
-                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS", "CPF_ZYZ3_RES", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {
@@ -1314,9 +1322,9 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
         report += "zyzl/jit(" + code.backend + ") waves=" + std::to_string(1 << lw) + (code.compiled ? " [built] " : " [cached] ") + spec.body + "\n";
         built++;
     }
-    // 3 qubits: the two-ended ZYZ-form kernel where a launch of this many samples takes it by default (cpf_zyz3.h) - then nothing else
+    // 3 qubits: the two-ended ZYZ-form kernel (cpf_zyz3.h), the default at every number of samples - then nothing else
     // is built for the shape: the gate-by-gate kernels that read the block count from the plan are part of the library
-    if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind) && zyz3_by_samples(&pl, num_samples)) {
+    if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind)) {
         const int M = zyz3_cut(&pl, num_samples), rot = dense_rot_code(&pl), pairs = zyz3_pairs(&pl, num_samples);
         if (!cpf_zyz3_has_aot(rot, pl.K, M, pairs, pl.layer_ud)) {
             const cpf_jit::Spec spec = zyz3_jit_spec(rot, pl.K, M, pairs, pl.layer_ud);

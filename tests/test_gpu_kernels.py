@@ -6,6 +6,7 @@ pytestmark = pytest.mark.gpu
 
 import oracle  # noqa: E402
 from oracle import Oracle  # noqa: E402
+import zyz3_shape  # noqa: E402
 
 
 def _rand_unitary(n, seed):
@@ -274,7 +275,7 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
 
 @pytest.mark.parametrize('ent,layer,K,rot,S,kind', [
     ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'zyz3/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'zyz3/jit(hipcc) waves=2 K cut=6'),
-    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=4'),        # the local-minimum study's shape: shipped
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=3'),        # the local-minimum study's shape: shipped
     ('cz', [[0, 1], [0, 2], [1, 2]], 15, 'xyz', 3000, 'zyz3/jit'),                               # a block count nobody shipped, SIMDs full
     ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'zyz3/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'zyz3/jit'),
     ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'zyzl/jit'),
@@ -507,7 +508,7 @@ def test_shipped_block_count_specialised_kernels(layer, K, rot, S, monkeypatch, 
     monkeypatch.setenv('CPF_JIT_FORBID_COMPILE', '1')
     target = _rand_unitary(3, 43)
     T = 14
-    variant = f'zyz3/jit(hipcc) waves=2 K cut={(9 * K + (12 if S <= 512 else 10)) // 20}'         # one sample per CU: the balanced cut
+    variant = 'zyz3/jit(hipcc)' + zyz3_shape.tail(K, S)
     before = _ffi.lib().cpf_jit_compiles()
     orc = Oracle(layer, K, target, rot, num_gd_iterations=T, r=0.004)
     eng = _engine(layer, K, target, rot, num_gd_iterations=T, r=0.004)
@@ -555,7 +556,7 @@ def test_every_shipped_block_count(layer, rot, monkeypatch, tune):
         out = {k: v.cpu().numpy() for k, v in eng.optimize(init, keep_history=True).items()}
         v = eng.last_variant()
         builtin = rot == 'xyz' and K == (12 if len(layer) == 2 else 16)
-        assert v == ('zyz3/aot' if builtin else 'zyz3/jit(hipcc)') + f' waves=2 K cut={(9 * K + 12) // 20}', (K, v)
+        assert v == ('zyz3/aot' if builtin else 'zyz3/jit(hipcc)') + zyz3_shape.tail(K, 3), (K, v)
         err = np.abs(out['history_regloss'] - ref['history_loss'])
         # first loss to rounding; later iterates: Adam turns a rounding-level gradient component into a full step whose sign is
         # noise (K = 14, 'xyz', sample 1: a component of 7e-9 - the float32 oracle itself leaves the float64 trajectory by 8e-4

@@ -252,10 +252,8 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
 
 
 def test_block_count_specialised_kernels_per_regime(tmp_path):
-    """3 qubits: the K-specialised two-ended kernel a launch would look up, by samples per CU (cpflow_amd.hip
-    jit_candidates with k_mode 1; MSTORE = form + 4 K + the balanced-cut bit 17): one sample per CU -> stored states and the
-    balanced cut, two -> that with both samples in one workgroup, a few per CU -> stored states, saturated -> un-apply.  All of them are in the shipped cache for the block
-    counts of an adaptive search (build.precompile_shapes)."""
+    """3 qubits: the K-specialised two-ended ZYZ-form kernel a launch would look up, by samples per CU (cpflow_amd.hip zyz3_cut /
+    zyz3_pairs).  All of them are in the shipped cache for the block counts of an adaptive search (build.precompile_shapes)."""
     import json
     import shutil
     import subprocess
@@ -273,17 +271,16 @@ def test_block_count_specialised_kernels_per_regime(tmp_path):
         assert r.returncode == 0, r.stderr
         lines = json.loads(r.stdout.strip().splitlines()[-1])
         return re.sub(r'jit\(\w+\)', 'jit(hipcc)', lines[0].replace('[built]', '[cached]')) if lines else ''
-    # round 5: while every sample of the launch is resident at once (and beyond that up to 12 blocks) the shape runs on the two-ended
-    # ZYZ-form kernel, specialised on the block count and the cut; the gate-by-gate two-ended kernel keeps the saturated launches
-    # (block count, cut = blocks of wave A, samples per workgroup) are template arguments: one sample per CU -> the balanced cut; two
-    # per CU -> both in one workgroup, sharing the owner wave; more -> the cut measured best under contention
+    # round 5: every 3-qubit shape runs on the two-ended ZYZ-form kernel; block count, cut (= blocks of wave A) and samples per
+    # workgroup are template arguments: one sample per CU -> (K - 1) / 2; two per CU -> both in one workgroup, sharing the owner of
+    # the block angles, K / 2; up to four resident per CU -> 0.36 K; launches that run in rounds -> 0.43 K (cpflow_amd.hip zyz3_cut)
     assert kernels(14, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 1, 0, 1, 1, 2>')
-    assert kernels(14, 512).startswith('zyz3/jit(hipcc) waves=2 K cut=6 pairs=2 [cached] cpf::zyz3_body<8451, 14, 6, 2, 0, 1, 1, 2>')
-    assert kernels(14, 700).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 1, 0, 1, 1, 2>')
+    assert kernels(14, 512).startswith('zyz3/jit(hipcc) waves=2 K cut=7 pairs=2 [cached] cpf::zyz3_body<8451, 14, 7, 2, 0, 1, 1, 2>')
+    assert kernels(14, 700).startswith('zyz3/jit(hipcc) waves=2 K cut=5 [cached] cpf::zyz3_body<8451, 14, 5, 1, 0, 1, 1, 2>')
     assert kernels(12, 8192) == ''                                                          # config 2's shape: built into the library
-    assert kernels(14, 8192).startswith(f'split/jit(hipcc) waves=2 K [cached] cpf::split_body<8451, 1, {1 + 4 * 14}, 0, 1, 1, 2>')
+    assert kernels(14, 8192).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 1, 0, 1, 1, 2>')
     assert kernels(20, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=9 [cached]')
-    assert kernels(24, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=11 [cached]')         # 63 KB of LDS per sample
+    assert kernels(24, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=11 [cached]')         # 54 KB of LDS per sample
     from cpflow_amd.build import precompile_shapes
     ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
     assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 400, 700, 2048, 8192}
