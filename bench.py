@@ -116,13 +116,16 @@ def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
 
 def executed_flops(variant, num_qubits, num_blocks, algorithmic):
     """Approximate flops the kernel EXECUTES per sample-step, for the ZYZ-form kernels only (None otherwise: the gate-by-gate
-    kernels execute SURVEY's count and more).  The generated group routines (cpf_zyz_asm.h) spend 15 + 51 packed instructions per
-    four amplitudes and block = 13 + 47 flop per amplitude with a packed multiply counted as 2 and a packed FMA as 4; the
-    surface gates and per-step phases are left at SURVEY's figure."""
-    if not variant.startswith(('zyz/', 'zyzl/')):
+    kernels execute SURVEY's count and more), a packed multiply counted as 2 and a packed FMA as 4.  zyz/, zyzl/: the generated
+    group routines (cpf_zyz_asm.h) spend 15 + 51 packed instructions per four amplitudes and block = 13 + 47 flop per amplitude.
+    zyz3/ (cpf_zyz3.h): per amplitude and block 14 forward (one complex multiply, two real stages), 34 in the gradient half (the
+    same on the other matrix, the three products behind the 7 generator sums) and 7 adds in the row sums = 55.  The surface gates
+    and per-step phases are left at SURVEY's figure."""
+    if not variant.startswith(('zyz/', 'zyzl/', 'zyz3/')):
         return None
     n2 = float(1 << (2 * num_qubits))
-    return algorithmic - 3.0 * n2 * 32.0 * num_blocks + n2 * 60.0 * num_blocks
+    per_amp = 55.0 if variant.startswith('zyz3/') else 60.0
+    return algorithmic - 3.0 * n2 * 32.0 * num_blocks + n2 * per_amp * num_blocks
 
 
 def other_configs(workloads, TemplateEngine, torch, launches=3):
@@ -302,7 +305,7 @@ def main():
                                  f'{flops:.0f} flop/sample-step; traffic = HBM bytes per launch from the stored rocprofv3 '
                                  '--pmc passes named in traffic_source (not measured in this run); flop/sample-step is SURVEY '
                                  '8(d)\'s algorithmic count (one dense 4x4 per block and pass) whatever algebra the kernel runs - the '
-                                 'ZYZ-form kernels (zyz/, zyzl/) execute fewer (DESIGN.md section 4)',
+                                 'ZYZ-form kernels (zyz/, zyzl/, zyz3/) execute fewer: frac_executed (DESIGN.md section 4)',
                          'kernel': eng.last_variant()},
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes,
                     'achieved_GBps': alg_bytes / (k_ms * 1e-3) / 1e9, 'peak_GBps': HBM_PEAK_GBS,

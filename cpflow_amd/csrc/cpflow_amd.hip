@@ -781,7 +781,7 @@ int64_t zyz3_per_cu(const cpf_plan* plan, int64_t S) { return (S + plan->num_cu 
 int64_t zyz3_max_resident(const cpf_plan* plan) { return std::min<int64_t>(16, plan->lds_per_cu / ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4)); }
 bool zyz3_all_resident(const cpf_plan* plan, int64_t S) { return zyz3_per_cu(plan, S) <= zyz3_max_resident(plan); }
 int zyz3_pairs(const cpf_plan* plan, int64_t S) {
-    int pairs = (2 * plan->K <= 32 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;
+    int pairs = (plan->K <= 14 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;      // 16 blocks: measured level with one sample per workgroup
     { const TuneVal e = tuning("CPF_ZYZ3_PAIRS"); if (e) pairs = (e[0] == '2' && 2 * plan->K <= 32) ? 2 : 1; }
     if ((int64_t)2 * cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) pairs = 1;
     return pairs;

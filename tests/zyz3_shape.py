@@ -13,7 +13,7 @@ def lds_bytes(K):
 
 def pairs(K, S):
     per_cu = -(-S // NUM_CU)
-    return 2 if (2 * K <= 32 and per_cu == 2 and 2 * lds_bytes(K) <= LDS_PER_CU) else 1
+    return 2 if (K <= 14 and per_cu == 2 and 2 * lds_bytes(K) <= LDS_PER_CU) else 1
 
 
 def cut(K, S):
