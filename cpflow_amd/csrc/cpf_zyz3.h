@@ -61,16 +61,17 @@ constexpr int ZYZ3_ROW = 68;                     // floats per row of shares: 64
 
 // floats of LDS per sample of an instance with K blocks (Zyz3Lds<K>::TOTAL)
 __host__ __device__ constexpr int zyz3_lds_floats(int K) {
-    const int rows = 10 + 7 * K;
-    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 4, states = (tot + rows + 3) & ~3;
-    return states + 128 * 2 + rows * ZYZ3_ROW;
+    const int rows = 10 + 7 * K, srows = 7 + 5 * K;
+    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 4, states = (tot + rows + 1 + 3) & ~3;
+    return states + 128 * 2 + srows * ZYZ3_ROW;
 }
 __host__ __device__ constexpr bool zyz3_supported(int K, int n_rot) { return K >= 2 && 2 * K <= 64 && n_rot >= 1 && n_rot <= 3; }
 
 template <int K>
 struct Zyz3Lds {                                  // float offsets, per sample; [0, 28) = penalty table
     static constexpr int up4(int x) { return (x + 3) & ~3; }
-    static constexpr int ROWS = 10 + 7 * K;       // 9 surface sums, S11 of block 0, then 7 per block (Px Py Pz up, Px Py Pz dn, S11 of the next block)
+    static constexpr int ROWS = 10 + 7 * K;       // sums: 9 of the surface slice, S11 of block 0, then 7 per block (Px Py Pz up, Px Py Pz dn, S11 of the next block)
+    static constexpr int SROWS = 7 + 5 * K;       // rows of shares: Px Py of the three qubits and u at the surface slice, then 5 per block (Px Py up, Px Py dn, u)
     static constexpr int REC1 = PEN_FLOATS;       // (2 K + 1) x {l0, l1}: left factors of a side; the last entry is the identity ("no previous side")
     static constexpr int PV = REC1 + 8 * K + 4;   // K penalty values (padded to a multiple of 4)
     static constexpr int PTH = PV + up4(K);       // the K CP angles (wave B -> wave A, which evaluates the penalty)
@@ -78,11 +79,12 @@ struct Zyz3Lds {                                  // float offsets, per sample; 
     static constexpr int TAB = PSL + up4(K);      // K x 4 entries x {d.re, d.im, t_up signed, t_dn signed}
     static constexpr int SURFM = TAB + 16 * K;    // 3 x {S, F S} x 2x2 complex: both variants of each surface matrix
     static constexpr int MSF = SURFM + 48;        // the three flip parities (floats 0 / 1), one spare
-    static constexpr int TOT = MSF + 4;           // ROWS row totals
-    static constexpr int STATES = up4(TOT + ROWS);           // 2 x 64 x (re, im): the two states at the cut, psi(s_{M-1}) and W(s_{M-1})
-    static constexpr int PART = STATES + 128 * 2;            // ROWS x ZYZ3_ROW
-    static constexpr int TOTAL = PART + ROWS * ZYZ3_ROW;
+    static constexpr int TOT = MSF + 4;           // the ROWS sums, one spare slot behind them for stores that mean nothing
+    static constexpr int STATES = up4(TOT + ROWS + 1);       // 2 x 64 x (re, im): the two states at the cut, psi(s_{M-1}) and W(s_{M-1})
+    static constexpr int PART = STATES + 128 * 2;            // SROWS x ZYZ3_ROW
+    static constexpr int TOTAL = PART + SROWS * ZYZ3_ROW;
     static constexpr int row_blk(int b) { return 10 + 7 * b; }
+    static constexpr int srow_blk(int b) { return 7 + 5 * b; }
     static_assert(TOTAL == zyz3_lds_floats(K), "the host's formula");
 };
 
@@ -190,8 +192,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     constexpr int LL = sizeof...(UD) / 2, K = KC, M = MC;
     constexpr int NR = rot_nr(ROT), ENT = rot_ent(ROT), NBP = 2 * NR + (ENT == 0 ? 1 : 0), NS = 9;
     constexpr int NITEM = 2 * K;                             // owner lanes of wave B: the sides
-    constexpr int ROWS = Lds::ROWS, RA = Lds::row_blk(M);     // rows [0, RA) are written and added by wave A, [RA, ROWS) by wave B
-    constexpr int NRA = (RA + 63) / 64, NRB = (ROWS - RA + 63) / 64;
+    constexpr int SROWS = Lds::SROWS, SA = Lds::srow_blk(M);   // rows of shares [0, SA) are written and added by wave A, [SA, SROWS) by wave B
+    constexpr int NRA = (SA + 63) / 64, NRB = (SROWS - SA + 63) / 64;
     static_assert(LL > 0 && NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     static_assert(M >= 1 && M < K && NITEM <= 64, "both waves sweep at least one block; one owner lane per item");
     static_assert(PAIRS == 1 || (PAIRS == 2 && NITEM <= 32), "two samples per workgroup: the sides of each in half a wave");
@@ -212,11 +214,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     for (int q = 0; q < 3; q++) { lb[q] = (lane >> L::row_lane_bit(q)) & 1; sg[q] = lb[q] ? 1.f : -1.f; }
     const bool odd = lane & 1;
     const int col = L::col_index(lane, 0), row = L::row_index(lane, 0);
-    int kofs[LL]; float m11[LL]; f2 sgp[LL];                 // per layer position: the lane's table entry, its |11> mask, (sg[up], sg[dn])
+    int kofs[LL]; f2 sgp[LL];                                // per layer position: the lane's table entry, (sg[up], sg[dn])
     static_for([&](auto jj) __attribute__((always_inline)) {
         constexpr int J = decltype(jj)::value, UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
         kofs[J] = 4 * (2 * (lb[UP] ? 1 : 0) + (lb[DN] ? 1 : 0));
-        m11[J] = (lb[UP] && lb[DN]) ? 1.f : 0.f;
         sgp[J] = f2{sg[UP], sg[DN]};
     }, typename make_iseq<LL>::type{});
     f2* sp = reinterpret_cast<f2*>(smem + Lds::STATES) + lane;             // sp[0]: wave A's state at the cut, sp[64]: wave B's
@@ -228,21 +229,62 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
     auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // one wave adds rows [r_lo, r_hi) of the shares (its own lanes wrote them: in order, no barrier), one lane per row
-    auto row_sums = [&](int r_lo, int r_hi, int nrnd) __attribute__((always_inline)) {
-        lds_fence();
-        for (int r = 0; r < nrnd; r++) {
-            const int rowi = r_lo + lane + 64 * r;
-            const int rc = rowi < r_hi ? rowi : r_hi - 1;
-            const float4* src = reinterpret_cast<const float4*>(smem + Lds::PART + ZYZ3_ROW * rc);
-            f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const float4 v = src[k];
-                a0 += f2{v.x, v.y}; a1 += f2{v.z, v.w};
+    // static structure: qubit of side w (block w >> 1, side w & 1)
+    auto qubit_of = [&](int w) {
+        int r = 0;
+        static_for([&](auto jj) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj)::value;
+            if ((w >> 1) % LL == J) r = (w & 1) ? PL::v[2 * J + 1] : PL::v[2 * J];
+        }, typename make_iseq<LL>::type{});
+        return r;
+    };
+    // One wave adds rows [r_lo, r_hi) of the shares (its own lanes wrote them: in order, no barrier), one lane per row, 64 rows a
+    // round.  A row is added in eight parts - by the lane bits 0, 1, 3 of its entries, the row qubits' bits - because a u row
+    // (u = Im conj(w) psi at every lane) stands for three signed sums: Pz of a qubit is u over the lanes with the qubit's bit clear
+    // minus u over the others, and the |11> sum of a pair is u over the lanes with both bits set.  Writing u once instead of three
+    // signed copies takes two of a block's seven 256-byte LDS stores out of the sweeps (config 2: 4.76 -> 4.66 ms); the parts cost the
+    // adding lane nothing (the same 32 packed adds) and the combinations ~20 instructions per wave and step.
+    struct RowK { int row, d_tot, dz0, dz1, dz2, ds; float w01, w02, w12; };
+    auto row_consts = [&](int r_lo, int r_hi, int r) {
+        RowK k;
+        const int sr = r_lo + lane + 64 * r, none = Lds::TOT + Lds::ROWS;
+        k.row = sr < r_hi ? sr : r_hi - 1;
+        k.d_tot = k.dz0 = k.dz1 = k.dz2 = k.ds = none;
+        k.w01 = k.w02 = k.w12 = 0.f;
+        if (sr < r_hi) {
+            const int b = sr < 7 ? -1 : (sr - 7) / 5, j = sr < 7 ? sr : (sr - 7) % 5;
+            const bool is_u = sr < 7 ? j == 6 : j == 4;
+            if (!is_u) k.d_tot = Lds::TOT + (b < 0 ? 3 * (j >> 1) + (j & 1) : Lds::row_blk(b) + 3 * (j >> 1) + (j & 1));
+            else {
+                int dz[3] = {none, none, none};
+                if (b < 0) { dz[0] = Lds::TOT + 2; dz[1] = Lds::TOT + 5; dz[2] = Lds::TOT + 8; }
+                else { dz[qubit_of(2 * b)] = Lds::TOT + Lds::row_blk(b) + 2; dz[qubit_of(2 * b + 1)] = Lds::TOT + Lds::row_blk(b) + 5; }
+                k.dz0 = dz[0]; k.dz1 = dz[1]; k.dz2 = dz[2];
+                if (b + 1 < K) {                             // the |11> sum of the NEXT block's pair
+                    k.ds = Lds::TOT + (b < 0 ? 9 : Lds::row_blk(b) + 6);
+                    const int qa = qubit_of(2 * (b + 1)), qb = qubit_of(2 * (b + 1) + 1), pr = (1 << qa) | (1 << qb);
+                    k.w01 = pr == 3 ? 1.f : 0.f; k.w02 = pr == 5 ? 1.f : 0.f; k.w12 = pr == 6 ? 1.f : 0.f;
+                }
             }
-            if (rowi < r_hi) smem[Lds::TOT + rowi] = (a0.x + a0.y) + (a1.x + a1.y);
         }
+        return k;
+    };
+    auto row_sums = [&](const RowK& k) __attribute__((always_inline)) {
+        const float4* src = reinterpret_cast<const float4*>(smem + Lds::PART + ZYZ3_ROW * k.row);
+        f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};      // lane bit 3 clear: (bits 1 0 = 00, 01), (10, 11); set: likewise
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float4 v = src[q];
+            if ((q >> 1) & 1) { b0 += f2{v.x, v.y}; b1 += f2{v.z, v.w}; }
+            else { a0 += f2{v.x, v.y}; a1 += f2{v.z, v.w}; }
+        }
+        const f2 t0 = a0 + b0, t1 = a1 + b1;
+        const float sa = (a0.x + a0.y) + (a1.x + a1.y), sb = (b0.x + b0.y) + (b1.x + b1.y);
+        smem[k.d_tot] = sa + sb;
+        smem[k.dz0] = (t0.x + t1.x) - (t0.y + t1.y);
+        smem[k.dz1] = (t0.x + t0.y) - (t1.x + t1.y);
+        smem[k.dz2] = sa - sb;
+        smem[k.ds] = fmaf(k.w01, t1.y, fmaf(k.w02, b0.y + b1.y, k.w12 * (b1.x + b1.y)));
     };
     const int iters = a.T > 0 ? a.T : 1;
 #ifdef CPF_STAMPS
@@ -338,10 +380,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         // (dead between the last barrier of a step and the gradient halves of the next).  A divergent region next to the loop's back
         // edge made the compiler split the loop by lanes - the barrier at its top then ran once per group of lanes.
         float* const pub = smem + (is_qubit ? Lds::SURFM : Lds::PART) + 16 * lane;
-        static_assert(Lds::ROWS * ZYZ3_ROW >= 64 * 16, "scratch for the lanes without a qubit");
+        static_assert(Lds::SROWS * ZYZ3_ROW >= 64 * 16, "scratch for the lanes without a qubit");
         const unsigned flag_addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)(smem + Lds::MSF + 3);      // LDS byte address
-        float* const pen_dst = smem + (lane < K ? Lds::PV + lane : Lds::PART + 1024 + 2 * lane);
-        static_assert(Lds::ROWS * ZYZ3_ROW >= 1024 + 128 + (Lds::PSL - Lds::PV), "scratch for the lanes without a CP angle");
+        float* const pen_dst = smem + (lane < K ? Lds::PV + lane : Lds::PART + 2 * lane);      // (the scratch of the matrices again: stored later, read never)
+        static_assert(Lds::SROWS * ZYZ3_ROW >= 128 + (Lds::PSL - Lds::PV), "scratch for the lanes without a CP angle");
         auto publish_surface = [&]() __attribute__((always_inline)) {
             float sm[8];
             zyz::surface_matrix(sm, cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], 0);
@@ -351,6 +393,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             dst[2] = make_float4(-sm[4], -sm[5], -sm[6], -sm[7]);            // F S: row 0 = -row 1, row 1 = row 0
             dst[3] = make_float4(sm[0], sm[1], sm[2], sm[3]);
         };
+        RowK rka[NRA];
+#pragma unroll
+        for (int r = 0; r < NRA; r++) rka[r] = row_consts(0, SA, r);
         barrier();                                           // constant records of the set-up
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -422,8 +467,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             if (it + 1 == iters) break;
             CPF_STAMP(4)                                  // loss
             static_for([&](auto bb) __attribute__((always_inline)) {
-                constexpr int B = M - 1 - decltype(bb)::value, J = B % LL, JN = (B + 1) % LL;
-                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::row_blk(B);
+                constexpr int B = M - 1 - decltype(bb)::value, J = B % LL;
+                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::srow_blk(B);
                 const f2 o = own[B + 1];
                 // the partner lanes' psi(s_B) on the block's two qubits, straight from their registers (the state is no longer the
                 // sweep's live value, so the four moves wait for nothing and fill the sweep's dependency stalls): (re up, re dn), (im up, im dn)
@@ -431,33 +476,29 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 // Im / Re of conj(w) psi[partner] for both qubits at once; Im(conj(w) psi) at the lane
                 const f2 PX = pk_fma(splat(w.x), pim, -(splat(w.y) * pre));
                 const f2 PY = pk_fma(splat(w.x), pre, splat(w.y) * pim) * sgp[J];
-                const float u = fmaf(w.x, o.y, -w.y * o.x);
-                const f2 PZ = sgp[J] * splat(-u);
                 part[ZYZ3_ROW * (R0 + 0)] = PX.x;
                 part[ZYZ3_ROW * (R0 + 1)] = PY.x;
-                part[ZYZ3_ROW * (R0 + 2)] = PZ.x;
-                part[ZYZ3_ROW * (R0 + 3)] = PX.y;
-                part[ZYZ3_ROW * (R0 + 4)] = PY.y;
-                part[ZYZ3_ROW * (R0 + 5)] = PZ.y;
-                if constexpr (B + 1 < K) part[ZYZ3_ROW * (R0 + 6)] = m11[JN] * u;
+                part[ZYZ3_ROW * (R0 + 2)] = PX.y;
+                part[ZYZ3_ROW * (R0 + 3)] = PY.y;
+                part[ZYZ3_ROW * (R0 + 4)] = fmaf(w.x, o.y, -w.y * o.x);
                 z3_stage<DN, true>(w, ent[B].w);
                 z3_stage<UP, true>(w, ent[B].z);
                 w = z3_cmul_conj(f2{ent[B].x, ent[B].y}, w);
             }, typename make_iseq<M>::type{});
             {   // the surface slice s_-1: all three qubits, and the |11> sum of block 0
                 const f2 o = own[0];
-                const float u = fmaf(w.x, o.y, -w.y * o.x);
                 static_for([&](auto qq) __attribute__((always_inline)) {
                     constexpr int Q = decltype(qq)::value;
                     const f2 psq = {z3_partner<Q>(o.x), z3_partner<Q>(o.y)};
                     const f2 zq = w * swp(psq), yq = w * psq;
-                    part[ZYZ3_ROW * (3 * Q + 0)] = zq.x - zq.y;
-                    part[ZYZ3_ROW * (3 * Q + 1)] = sg[Q] * (yq.x + yq.y);
-                    part[ZYZ3_ROW * (3 * Q + 2)] = -sg[Q] * u;
+                    part[ZYZ3_ROW * (2 * Q + 0)] = zq.x - zq.y;
+                    part[ZYZ3_ROW * (2 * Q + 1)] = sg[Q] * (yq.x + yq.y);
                 }, typename make_iseq<3>::type{});
-                part[ZYZ3_ROW * 9] = m11[0] * u;
+                part[ZYZ3_ROW * 6] = fmaf(w.x, o.y, -w.y * o.x);
             }
-            row_sums(0, RA, NRA);
+            lds_fence();
+#pragma unroll
+            for (int r = 0; r < NRA; r++) row_sums(rka[r]);
             CPF_STAMP(5)                                  // gradient half + row sums
             barrier();
             CPF_STAMP(6)
@@ -488,15 +529,6 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     const int64_t os_idx = ovs ? os_raw : (int64_t)a.nsamples - 1;
     const float2 vt_ = a.target[row * 8 + col];
     const f2 vt = {vt_.x, vt_.y};
-    // static structure: qubit of side w; every side on a qubit as a bit mask
-    auto qubit_of = [&](int w) {
-        int r = 0;
-        static_for([&](auto jj) __attribute__((always_inline)) {
-            constexpr int J = decltype(jj)::value;
-            if ((w >> 1) % LL == J) r = (w & 1) ? PL::v[2 * J + 1] : PL::v[2 * J];
-        }, typename make_iseq<LL>::type{});
-        return r;
-    };
     int lastside[3] = {-1, -1, -1}, firstside[3] = {-1, -1, -1};
     for (int w = 2 * K - 1; w >= 0; w--) firstside[qubit_of(w)] = w;
     for (int w = 0; w < 2 * K; w++) lastside[qubit_of(w)] = w;
@@ -537,6 +569,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     for (int q = 0; q < 3; q++) lfin_off[q] = Lds::REC1 + 4 * (lastside[q] >= 0 ? lastside[q] : 2 * K) + 2 * (lb[q] ? 1 : 0);
 
     if (owner_wave && il < 3 && firstside[il] < 0) osmem[Lds::MSF + il] = 0.f;      // a qubit no block touches is never flipped
+    RowK rkb[NRB];
+#pragma unroll
+    for (int r = 0; r < NRB; r++) rkb[r] = row_consts(SA, SROWS, r);
     barrier();                                               // penalty table, constant records: written by wave A's lanes
 #ifdef CPF_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -648,8 +683,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         {
             f2 pp = z3_cmul_conj(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, psi_c);
             static_for([&](auto bb) __attribute__((always_inline)) {
-                constexpr int B = M + decltype(bb)::value, J = B % LL, JN = (B + 1) % LL;
-                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::row_blk(B);
+                    constexpr int B = M + decltype(bb)::value, J = B % LL;
+                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::srow_blk(B);
                 pp = z3_cmul(f2{ent[B - M].x, ent[B - M].y}, pp);
                 z3_stage<UP>(pp, ent[B - M].z);
                 z3_stage<DN>(pp, ent[B - M].w);
@@ -658,18 +693,16 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 // the roles swapped: Im / Re of conj(W[partner]) psi' (the sign of the y sums changes), Im(conj(W) psi') at the lane
                 const f2 PX = pk_fma(splat(pp.y), pre, -(splat(pp.x) * pim));
                 const f2 PY = pk_fma(splat(pp.x), pre, splat(pp.y) * pim) * -sgp[J];
-                const float u = fmaf(o.x, pp.y, -o.y * pp.x);
-                const f2 PZ = sgp[J] * splat(-u);
                 part[ZYZ3_ROW * (R0 + 0)] = PX.x;
                 part[ZYZ3_ROW * (R0 + 1)] = PY.x;
-                part[ZYZ3_ROW * (R0 + 2)] = PZ.x;
-                part[ZYZ3_ROW * (R0 + 3)] = PX.y;
-                part[ZYZ3_ROW * (R0 + 4)] = PY.y;
-                part[ZYZ3_ROW * (R0 + 5)] = PZ.y;
-                if constexpr (B + 1 < K) part[ZYZ3_ROW * (R0 + 6)] = m11[JN] * u;
+                part[ZYZ3_ROW * (R0 + 2)] = PX.y;
+                part[ZYZ3_ROW * (R0 + 3)] = PY.y;
+                part[ZYZ3_ROW * (R0 + 4)] = fmaf(o.x, pp.y, -o.y * pp.x);
             }, typename make_iseq<K - M>::type{});
         }
-        row_sums(RA, ROWS, NRB);
+        lds_fence();
+#pragma unroll
+        for (int r = 0; r < NRB; r++) row_sums(rkb[r]);
         CPF_STAMP(5)                                  // gradient half + row sums
         barrier();
         CPF_STAMP(6)
