@@ -33,8 +33,10 @@
 //     the e-pairs replaces a trip through LDS, and each lane writes two of the four entries a sweep lane reads with one
 //     ds_read_b128: (d.re, d.im, signed t_up, signed t_dn).  The common phase of a block's entries is left in (no loss sees it);
 //   * the flip bits of all sides are ONE ballot (all sides sit in wave B), pending parities a popcount against a per-lane mask;
-//   * T = sum conj(W) psi over the 64 lanes is two v_mfma_f32_16x16x4_f32 against a register of ones (the matrix core as an
-//     adder tree), both waves, identical arithmetic;
+//   * T = sum conj(W) psi over the 64 lanes: six DPP stages and a v_readlane per component, both waves, identical arithmetic.  Two
+//     v_mfma_f32_16x16x4_f32 against a register of ones (the matrix core as an adder tree, CPF_Z3_MFMA=1) are shorter for a wave on
+//     its own and longer where two waves share a SIMD and its matrix pipe: config 2 4.65 against 4.61 ms, config 3's share 5.13
+//     against 5.01, 256 samples 4.10 against 4.14;
 //   * the penalty sum is K broadcast LDS reads in each wave (no cross-lane instruction);
 //   * everything that is not a block's side belongs to wave A, whose owner phase runs beside wave B's: the surface gates (chain
 //     rule, Adam, sin / cos, the two variants S and F S of each surface matrix - wave B only publishes the three flip parities) and
@@ -133,7 +135,7 @@ __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp
 // result registers.  Lanes are paired first (even lanes carry the real parts, odd lanes the imaginary parts), so one instruction
 // serves both components; a second one adds the four lane groups.
 #ifndef CPF_Z3_MFMA
-#define CPF_Z3_MFMA 1            // A/B: 0 = six DPP stages + v_readlane (cpf_device.h wave_sum2)
+#define CPF_Z3_MFMA 0            // A/B: 1 = the matrix core as an adder tree (below), 0 = six DPP stages + v_readlane (cpf_device.h wave_sum2)
 #endif
 #ifndef CPF_Z3_PRIO
 #define CPF_Z3_PRIO 1            // issue priority of wave B in launches whose workgroups are all resident (zyz3_body; 0 = never raised)
@@ -226,6 +228,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     penalty_table_init(smem, a, tid);
     if (tid == 0) *reinterpret_cast<float4*>(smem + Lds::REC1 + 8 * K) = make_float4(1.f, 0.f, 1.f, 0.f);
     if (tid < 3 * Lds::up4(K)) smem[Lds::PV + tid] = 0.f;
+    if (tid < 4) smem[Lds::MSF + tid] = 0.f;                 // [3]: the step counter wave A waits for - LDS keeps what the last workgroup left
 
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
     auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };

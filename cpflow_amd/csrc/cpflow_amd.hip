@@ -767,15 +767,15 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 
 // ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut, samples per workgroup and layer are compile-time constants of
 // every instance.  The cut M = blocks swept by wave A, which also owns the surface gates and the penalty; wave B owns the blocks'
-// angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named):
-//   one sample per CU      256 samples: 4.21 / 4.20 / 4.37 at 5 / 6 / 7; 100 samples of 14 blocks 4.41 / 4.46 at 6 / 7, of 24 blocks
-//                          5.93 / 5.97 at 11 / 12                                                      -> (K - 1) / 2
-//   two per CU             512: 4.67 / 4.69 / 4.91 at 3 / 4 / 5; with both samples in ONE workgroup (the hardware starts two-wave
-//                          workgroups one SIMD apart, which books a SIMD twice at two per CU) 4.56 / 4.40 at 5 / 6  -> K / 2, pairs
-//   up to four, resident   1024: 4.78 / 4.76 / 5.02 / 5.13 at 3 / 4 / 5 / 6; config 3's shape (16 blocks) 512: 5.48 / 5.46 / 5.54
-//                          at 5 / 6 / 7, 1024: 5.61 / 5.55 at 5 / 6; 1000 samples of 8 CZ blocks 4.00 / 4.01 at 2 / 3 -> 0.36 K
-//   more                   1280: 7.09 / 6.89 at 4 / 5; 2048: 12.41 / 12.18; 4096: 21.89 / 21.49; config 3's shape 4096: 27.7 /
-//                          26.7 at 6 / 7                                                               -> 0.43 K
+// angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named; profiles/r05_cfg2_levers_ab.txt):
+//   one sample per CU      256 samples: 4.32 / 4.08 / 4.07 at 4 / 5 / 6; 100 samples of 14 blocks 4.40 / 4.24 / 4.23 at 5 / 6 / 7, of
+//                          24 blocks 5.71 / 5.63 / 5.61 at 10 / 11 / 12                                  -> (K - 1) / 2
+//   two per CU             512: 4.70 at 4; with both samples in ONE workgroup (the hardware starts two-wave workgroups one SIMD
+//                          apart, which books a SIMD twice at two per CU) 4.42 / 4.35 at 5 / 6           -> K / 2, pairs
+//   more, all resident     1024: 4.65 / 4.68 at 3 / 4 (4.90 at 5); 1536: 6.42 / 6.52 / 6.51 at 3 / 4 / 5; config 3's shape (16 blocks) 512: 5.16 / 5.21 / 5.32 at 5 / 6 / 7;
+//                          1000 samples of 8 CZ blocks 4.02 / 4.19 at 2 / 3                              -> 0.33 K
+//   in rounds              2048: 10.16 / 10.22 / 11.09 at 4 / 5 / 6; 4096: 22.70 / 21.75 (both at six resident per CU);
+//                          config 3's shape 4096: 23.2 / 22.6 at 6 / 7                                   -> 0.43 K
 // CPF_ZYZ3_M overrides the cut, CPF_ZYZ3_PAIRS the samples per workgroup, CPF_ZYZ3_RES the workgroups resident per CU.
 int64_t zyz3_per_cu(const cpf_plan* plan, int64_t S) { return (S + plan->num_cu - 1) / plan->num_cu; }
 int64_t zyz3_max_resident(const cpf_plan* plan) { return std::min<int64_t>(16, plan->lds_per_cu / ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4)); }
@@ -789,20 +789,21 @@ int zyz3_pairs(const cpf_plan* plan, int64_t S) {
 int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
     const int64_t per_cu = zyz3_per_cu(plan, S);
-    int m = per_cu <= 1 ? (K - 1) / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : ((per_cu <= 4 && zyz3_all_resident(plan, S)) ? (36 * K + 50) / 100 : (43 * K + 50) / 100));
+    int m = per_cu <= 1 ? (K - 1) / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K) / 100 : (43 * K + 50) / 100));
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }
-// Dynamic LDS per workgroup.  A launch of more workgroups than fit at once runs in rounds (every workgroup takes the same time), so
-// what is resident per CU is evened out over the rounds by asking for more LDS than the kernel needs: 2048 samples of config 2's
-// shape (8 per CU, 5 fit) run as 4 + 4 instead of 5 + 3.
+// Dynamic LDS per workgroup: what the kernel needs.  CPF_ZYZ3_RES=r (A/B) asks for more, so that only r workgroups are resident per
+// CU: evening the residency out over the rounds of an oversubscribed launch was measured and lost to simply keeping every slot full
+// (config 2's shape, 7 workgroups fit per CU: 2048 samples 10.3 ms at 7 + 1 against 12.1 at 4 + 4; 4096 samples 18.4 at 7 + 7 + 2
+// against 18.6 at 6 + 6 + 4 and 23.4 at 4 x 4).
 size_t zyz3_lds_request(const cpf_plan* plan, int64_t S, int pairs) {
-    const int64_t lds1 = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 * pairs, per_cu = (zyz3_per_cu(plan, S) + pairs - 1) / pairs;
-    const int64_t fit = std::max<int64_t>(1, std::min<int64_t>(16 / pairs, plan->lds_per_cu / lds1));
-    int64_t res = per_cu <= fit ? 0 : (per_cu + (per_cu + fit - 1) / fit - 1) / ((per_cu + fit - 1) / fit);
+    (void)S;
+    const int64_t lds1 = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 * pairs;
+    int64_t res = 0;
     { const TuneVal e = tuning("CPF_ZYZ3_RES"); if (e) res = atoi(e.s.c_str()); }
-    if (res <= 0 || res >= fit) return (size_t)lds1;
-    return (size_t)std::max<int64_t>(lds1, (plan->lds_per_cu / res) & ~(int64_t)255);
+    if (res <= 0 || res * lds1 > plan->lds_per_cu) return (size_t)lds1;
+    return (size_t)std::max<int64_t>(lds1, (plan->lds_per_cu / res - 1024) & ~(int64_t)255);      // (not the whole share: a CU keeps a little LDS back)
 }
 cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<int>& ud) {
     cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M, pairs}, ud), 128 * pairs};

@@ -275,7 +275,7 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
 
 @pytest.mark.parametrize('ent,layer,K,rot,S,kind', [
     ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'zyz3/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'zyz3/jit(hipcc) waves=2 K cut=6'),
-    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=3'),        # the local-minimum study's shape: shipped
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=2'),        # the local-minimum study's shape: shipped
     ('cz', [[0, 1], [0, 2], [1, 2]], 15, 'xyz', 3000, 'zyz3/jit'),                               # a block count nobody shipped, SIMDs full
     ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'zyz3/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'zyz3/jit'),
     ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'zyzl/jit'),
@@ -1083,6 +1083,27 @@ def test_two_ended_zyz_kernel_matches_oracle(layer, K, rot, ent, cut, tune):
     out1 = {k: v.cpu().numpy() for k, v in eng1.optimize(init).items()}
     assert eng1.last_variant().startswith('zyz3/'), eng1.last_variant()
     assert np.abs(out1['regloss'][:, 0] - out['regloss'][:, 0]).max() == 0 and (out1['params'][:, 1] == init).all()
+
+
+@pytest.mark.gpu
+def test_two_ended_zyz_kernel_relaunched_with_one_iteration(tune):
+    """Wave A of the two-ended ZYZ-form kernel waits for a step counter that wave B writes to LDS (the hand-off of the CP angles for the
+    penalty, cpf_zyz3.h).  LDS keeps what the previous workgroup left there, and a launch of ONE iteration leaves exactly the value
+    the next launch's first step waits for: the counter is cleared in the set-up.  Three one-iteration launches back to back, more
+    workgroups than fit at once, with the penalty on, against the oracle."""
+    layer, K, rot = [[0, 1], [1, 2]], 12, 'xyz'
+    target = _rand_unitary(3, 61)
+    tune.set('CPF_ZYZ3', '1')
+    orc = Oracle(layer, K, target, rot, num_gd_iterations=1, r=0.05)
+    eng = _engine(layer, K, target, rot, num_gd_iterations=1, r=0.05)
+    for seed in (1, 2, 3):
+        init = orc.initial_angles(seed, 3000)
+        out = {k: v.cpu().numpy() for k, v in eng.optimize(init).items() if v is not None}
+        assert eng.last_variant().startswith('zyz3/'), eng.last_variant()
+        ref = orc.run(init[:64], np.float64)
+        assert np.abs(out['regloss'][:64] - ref['regloss']).max() < 1e-5 and np.abs(out['reg'][:64] - ref['reg']).max() < 1e-6
+        full = orc.run(init[-64:], np.float64)
+        assert np.abs(out['regloss'][-64:] - full['regloss']).max() < 1e-5 and np.abs(out['reg'][-64:] - full['reg']).max() < 1e-6
 
 
 @pytest.mark.gpu

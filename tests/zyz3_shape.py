@@ -22,8 +22,8 @@ def cut(K, S):
         m = (K - 1) // 2
     elif pairs(K, S) == 2:
         m = K // 2
-    elif per_cu <= 4 and per_cu <= fit:
-        m = (36 * K + 50) // 100
+    elif per_cu <= fit:
+        m = (33 * K) // 100
     else:
         m = (43 * K + 50) // 100
     return max(1, min(K - 1, m))

@@ -112,8 +112,11 @@ def cmd_knobs(args):
     T = eng.num_gd_iterations
     init = eng.initial_angles(0, S)
     res, var, stats = {c: [] for c in combos}, {}, {}
+    keys = {kv.split('=', 1)[0] for c in combos for kv in c.split(',')}
     for _ in range(5):
         for c in combos:
+            for k in keys:                       # a switch one combination sets must not leak into the next
+                os.environ.pop(k, None)
             for kv in c.split(','):
                 k, v = kv.split('=', 1)
                 os.environ[k] = v
