@@ -172,8 +172,10 @@ def cmd_fuzz(args):
     N = int(args[0]) if args else 24
     rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 0)
     ROTS = ['xyz', 'xz', 'yz', 'zxz', 'xyz', 'z', 'yxz', 'xy', 'zyx']
-    VARIANTS = [dict(CPF_PSTORE='1', CPF_KSPEC='1', CPF_JIT_K='1'), dict(CPF_PSTORE='0', CPF_KSPEC='0', CPF_JIT_K='0'),
-                dict(CPF_PSTORE='1', CPF_KSPEC='0', CPF_JIT_K='0'), dict(CPF_SPLIT='0')]
+    # 3 qubits: the default (the two-ended ZYZ-form kernel where it serves the case), that kernel at a random cut, and the
+    # gate-by-gate families behind their switches
+    VARIANTS = [dict(), dict(CPF_ZYZ3='1', CPF_ZYZ3_M='?'), dict(CPF_PSTORE='1', CPF_KSPEC='1', CPF_JIT_K='1'),
+                dict(CPF_PSTORE='0', CPF_KSPEC='0', CPF_JIT_K='0'), dict(CPF_SPLIT='0')]
     bad, t0 = 0, time.time()
     for _case in range(N):
         n = int(rng.choice([int(x) for x in os.environ['FUZZ_NS'].split(',')] if os.environ.get('FUZZ_NS') else [2, 3, 3, 3, 4, 4, 5, 6]))
@@ -210,8 +212,9 @@ def cmd_fuzz(args):
         ref = orc.run(init[:3], np.float64, keep_history=True)
         frozen = None if mask is None else np.broadcast_to(mask, (S, len(mask))).copy()
         for v in (VARIANTS if n == 3 else VARIANTS[:1]):
-            for k in ('CPF_PSTORE', 'CPF_KSPEC', 'CPF_JIT_K', 'CPF_SPLIT'):
+            for k in ('CPF_PSTORE', 'CPF_KSPEC', 'CPF_JIT_K', 'CPF_SPLIT', 'CPF_ZYZ3', 'CPF_ZYZ3_M'):
                 os.environ.pop(k, None)
+            v = {k: (str(int(rng.integers(1, K))) if x == '?' else x) for k, x in v.items()}
             os.environ.update(v)
             sync_tuning()
             eng = TemplateEngine(layer, K, target, rot, num_gd_iterations=T, r=r, entangler=ent, loss=loss)
