@@ -96,6 +96,16 @@ def precompile_shapes():
     return shapes
 
 
+def _headers_tag():
+    """Content hash of the kernel headers (a checkout or a touch changes modification times, not this)."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in sorted(d for d in DEPS if d.endswith('.h') and os.sep + 'csrc' + os.sep in d):
+        with open(d, 'rb') as f:
+            h.update(os.path.basename(d).encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
 def precompile(shapes=None, workers=None, verbose=True):
     """Fill cpflow_amd/jit_cache/ with the runtime-specialised kernels of `shapes` (no GPU needed: hipcc
     cross-compiles), so that a GPU box never compiles them.  One process per shape, `workers` at a time."""
@@ -106,7 +116,7 @@ def precompile(shapes=None, workers=None, verbose=True):
     os.chmod(JIT_DIR, 0o700)
     # code objects are keyed by a hash of the kernel headers: after a header edit every shipped object is stale
     # (the kernel headers under csrc/: the public header include/cpflow_amd.h is not part of any kernel)
-    stamp, tag = os.path.join(JIT_DIR, '.stamp'), str(max(os.path.getmtime(d) for d in DEPS if d.endswith('.h') and os.sep + 'csrc' + os.sep in d))
+    stamp, tag = os.path.join(JIT_DIR, '.stamp'), _headers_tag()
     if not os.path.exists(stamp) or open(stamp).read() != tag:
         for f in os.listdir(JIT_DIR):
             if f.endswith('.hsaco') or '.tmp' in f:
