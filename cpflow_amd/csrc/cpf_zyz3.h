@@ -5,9 +5,10 @@
 //
 // One amplitude of the 8 x 8 unitary per lane (Lay<3, 0>: every row qubit on a DPP-reachable lane bit), two waves per sample:
 //   wave A   psi(s_b), b = -1 .. M-1: the (flipped) product state of the surface gates, then blocks 0 .. M-1 applied;
-//            lanes 0 .. 2 OWN the surface angles of the three qubits, lanes 0 .. K-1 evaluate the penalty of the CP angles
+//            lanes 2 q, 2 q + 1 OWN the surface angles of qubit q, lanes 0 .. K-1 evaluate the penalty of the CP angles
 //   wave B   W(s_b), b = K-1 .. M-1: Vd = conj(dfin) V, then blocks K-1 .. M un-applied;
-//            lane w = 2 b + s OWNS the angles of side s of block b (side 0: the CP angle too)
+//            side w = 2 b + s of block b (its three rotation angles and, side 0, the CP angle) is OWNED by lanes 2 w, 2 w + 1
+//            (up to 16 blocks; by lane w alone beyond that and with two samples per workgroup)
 // with s_b the slice right after the two real stages of block b (cpf_zyz_math.h: what the sweeps hold there is the true state
 // up to pending flips and the left diagonals not yet merged).  A block is ONE complex multiply by the lane's merged phase and two
 // stages x += (+-t) x[partner] (two v_fmac_f32_dpp each): 6 vector instructions where the gate-by-gate sweep of cpf_split.h spends
@@ -38,6 +39,10 @@
 //     its own and longer where two waves share a SIMD and its matrix pipe: config 2 4.65 against 4.61 ms, config 3's share 5.13
 //     against 5.01, 256 samples 4.10 against 4.14;
 //   * the penalty sum is K broadcast LDS reads in each wave (no cross-lane instruction);
+//   * two lanes per item: the even lane owns angle slots 0 and 1, the odd lane slots 2 and 3, so that Adam and the sin / cos
+//     polynomials - the longest stretch of both owner phases - run on one packed pair per lane instead of two; the even lane fetches
+//     the other pair's (cos, sin) by DPP, does the rest as the item's main lane and hands two gradients back (config 2 4.72 -> 4.54 ms,
+//     config 3's share 5.02 -> 4.78, same box; halving the work of one wave alone does nothing: 4.58 -> 4.57 / 4.54 as prototypes);
 //   * everything that is not a block's side belongs to wave A, whose owner phase runs beside wave B's: the surface gates (chain
 //     rule, Adam, sin / cos, the two variants S and F S of each surface matrix - wave B only publishes the three flip parities) and
 //     the penalty of the CP angles, which wave B publishes right after its Adam update together with a step counter in LDS that
@@ -126,6 +131,11 @@ __device__ __forceinline__ float z3_partner(float v) {
     constexpr int CTRL = Q == 0 ? 0xB1 : (Q == 1 ? 0x4E : 0x128);       // quad_perm [1,0,3,2] / [2,3,0,1] / row_ror:8
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+template <int Q>
+__device__ __forceinline__ int z3_partner(int v) {
+    constexpr int CTRL = Q == 0 ? 0xB1 : (Q == 1 ? 0x4E : 0x128);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
 // value of lane ^ 1 (quad_perm [1,0,3,2]); every lane takes part
 __device__ __forceinline__ float z3_nb(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
@@ -181,11 +191,11 @@ __device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upp
 
 // ROT: rotation string and entangler (cpf_blocks.h rot_pack / rot_with_ent); KC: blocks; MC: blocks of wave A (1 .. KC-1);
 // PAIRS: samples per workgroup (1 or 2); UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20).
-// PAIRS = 2 (2 K <= 32 sides): four waves, two samples, each with its own copy of the LDS map - and ONE owner of the sides: wave B
-// of the first sample owns the block angles of both (lanes 0 .. 31 the first sample's sides, 32 .. 63 the second's).  The owner
-// phase is a stream of ~300 vector instructions per step whatever the number of busy lanes; at two samples per CU (each wave on a
-// SIMD of its own) sharing it pays (config 2's shape, 512 samples: 4.59 against 4.77 ms).  The second sample's wave B only sweeps;
-// each sample's wave A owns its own surface gates and penalty.
+// PAIRS = 2 (2 K <= 32 sides; a switch, no launch takes it by default): four waves, two samples, each with its own copy of the LDS
+// map - and ONE owner of the sides: wave B of the first sample owns the block angles of both (lanes 0 .. 31 the first sample's
+// sides, 32 .. 63 the second's; one lane per side).  At two samples per CU it beat one sample per workgroup while an owner lane
+// carried all four slots of its side (4.35 against 4.70 ms) and loses to the two-lane layout (4.46 against 4.28).  The second
+// sample's wave B only sweeps; each sample's wave A owns its own surface gates and penalty.
 template <int ROT, int KC, int MC, int PAIRS, int... UD>
 __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     using L = Lay<3, 0>;
@@ -193,7 +203,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     using Lds = Zyz3Lds<KC>;
     constexpr int LL = sizeof...(UD) / 2, K = KC, M = MC;
     constexpr int NR = rot_nr(ROT), ENT = rot_ent(ROT), NBP = 2 * NR + (ENT == 0 ? 1 : 0), NS = 9;
-    constexpr int NITEM = 2 * K;                             // owner lanes of wave B: the sides
+    // Two lanes per item where they fit (wave A always; wave B up to 16 blocks, one sample per workgroup): the even lane of a pair owns
+    // the item's angle slots 0 and 1, the odd lane slots 2 and 3 - so Adam and the sin / cos polynomials run once per step on ONE
+    // packed pair per lane instead of two (half of the owner phases' longest stretch; both waves have to shrink for the step to:
+    // timing prototypes 4.58 -> 4.57 / 4.54 ms for one wave alone, 4.24 for both).  The even lane is the item's main lane: it fetches
+    // its neighbour's (cos, sin) by DPP and does everything else as before; the odd lane gets its two gradients back the same way.
+    constexpr bool S2 = PAIRS == 1 && 4 * K <= 64;
+    constexpr int NITEM = (S2 ? 4 : 2) * K;                  // owner lanes of wave B: the sides (S2: two lanes per side)
     constexpr int SROWS = Lds::SROWS, SA = Lds::srow_blk(M);   // rows of shares [0, SA) are written and added by wave A, [SA, SROWS) by wave B
     constexpr int NRA = (SA + 63) / 64, NRB = (SROWS - SA + 63) / 64;
     static_assert(LL > 0 && NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
@@ -315,26 +331,39 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     };
     // Adam closes step `it - 1` (optax scale_by_adam, optimization.py:14-25: the same operations in the same order as the scalar form, per
     // half), then (cos, sin) of the half angles (slot 3: a CP angle, the full angle)
-    auto adam_sincos = [&](int it) __attribute__((always_inline)) {
+    // halfq: the lane owns slots 0 and 1 only (two lanes per item); sc01: what sin / cos take of slots 0, 1 (half angles; the full angle of a CP slot)
+    auto adam_sincos = [&](int it, auto halfq, f2 sc01) __attribute__((always_inline)) {
+        constexpr bool HALF = decltype(halfq)::value != 0;
         if (it > 0) {
             const float2 bc = const_load_f2(a.bias, it - 1);
             const f2 ibc = f2{__builtin_amdgcn_rcpf(bc.x), __builtin_amdgcn_rcpf(bc.y)};
-            const f2 m0 = pk_fma(splat(a.b1), mm01, splat(a.omb1) * g01), m1 = pk_fma(splat(a.b1), mm23, splat(a.omb1) * g23);
-            const f2 v0 = pk_fma(splat(a.b2), vv01, splat(a.omb2) * (g01 * g01)), v1 = pk_fma(splat(a.b2), vv23, splat(a.omb2) * (g23 * g23));
-            mm01 = m0; mm23 = m1; vv01 = v0; vv23 = v1;
-            const f2 h0 = v0 * splat(ibc.y), h1 = v1 * splat(ibc.y);
+            const f2 m0 = pk_fma(splat(a.b1), mm01, splat(a.omb1) * g01);
+            const f2 v0 = pk_fma(splat(a.b2), vv01, splat(a.omb2) * (g01 * g01));
+            mm01 = m0; vv01 = v0;
+            const f2 h0 = v0 * splat(ibc.y);
             const f2 d0 = f2{__builtin_amdgcn_sqrtf(h0.x), __builtin_amdgcn_sqrtf(h0.y)} + splat(a.eps);
-            const f2 d1 = f2{__builtin_amdgcn_sqrtf(h1.x), __builtin_amdgcn_sqrtf(h1.y)} + splat(a.eps);
             const f2 u0 = (m0 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)};
-            const f2 u1 = (m1 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
             th01 = pk_fma(nlr01, u0, th01);
-            th23 = pk_fma(nlr23, u1, th23);
+            if constexpr (!HALF) {
+                const f2 m1 = pk_fma(splat(a.b1), mm23, splat(a.omb1) * g23);
+                const f2 v1 = pk_fma(splat(a.b2), vv23, splat(a.omb2) * (g23 * g23));
+                mm23 = m1; vv23 = v1;
+                const f2 h1 = v1 * splat(ibc.y);
+                const f2 d1 = f2{__builtin_amdgcn_sqrtf(h1.x), __builtin_amdgcn_sqrtf(h1.y)} + splat(a.eps);
+                const f2 u1 = (m1 * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)};
+                th23 = pk_fma(nlr23, u1, th23);
+            }
         }
-        f2 s01, c01, s23, c23;
-        fast_sincos2(th01 * splat(0.5f), s01, c01);
-        fast_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);
+        f2 s01, c01;
+        fast_sincos2(th01 * sc01, s01, c01);
         cs[0][0] = c01.x; cs[0][1] = s01.x; cs[1][0] = c01.y; cs[1][1] = s01.y;
-        cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
+        if constexpr (HALF) {                               // slots 2, 3: the neighbouring (odd) lane's pair
+            cs[2][0] = z3_nb(c01.x); cs[2][1] = z3_nb(s01.x); cs[3][0] = z3_nb(c01.y); cs[3][1] = z3_nb(s01.y);
+        } else {
+            f2 s23, c23;
+            fast_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);
+            cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
+        }
     };
     // loss and best-iterate tracking from T and the penalty values of the lane's sample (both waves: the same instructions on the same numbers)
     auto track = [&](int it, float tr, float ti, const float4 (&pvq)[(K + 3) / 4], int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
@@ -375,14 +404,15 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         // barrier of a step, while wave B does the same for the blocks.  Lanes 0 .. K-1 also evaluate the penalty of the CP angles
         // (penalty.py:44-71) that wave B publishes: ~35 instructions that would otherwise sit in wave B's stream.
         const bool live = PAIRS == 1 || s_raw < a.nsamples;
-        const bool is_qubit = lane < 3;
-        if (is_qubit) { pj[0] = 3 * lane; pj[1] = 3 * lane + 1; pj[2] = 3 * lane + 2; }
+        const bool is_qubit = lane < 6 && !(lane & 1);     // the main lane of qubit lane >> 1; the odd lane beside it owns the third angle
+        const int qa = lane < 6 ? lane >> 1 : 0;
+        if (lane < 6) { if (lane & 1) pj[0] = 3 * qa + 2; else { pj[0] = 3 * qa; pj[1] = 3 * qa + 1; } }
         load_angles(s_idx, live);
         float my_flip = 0.f;
         // No branch on the lane here: every lane forms a matrix and stores it, the lanes that own no qubit into the rows of shares
         // (dead between the last barrier of a step and the gradient halves of the next).  A divergent region next to the loop's back
         // edge made the compiler split the loop by lanes - the barrier at its top then ran once per group of lanes.
-        float* const pub = smem + (is_qubit ? Lds::SURFM : Lds::PART) + 16 * lane;
+        float* const pub = smem + (is_qubit ? Lds::SURFM + 16 * qa : Lds::PART + 16 * lane);
         static_assert(Lds::SROWS * ZYZ3_ROW >= 64 * 16, "scratch for the lanes without a qubit");
         const unsigned flag_addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)(smem + Lds::MSF + 3);      // LDS byte address
         float* const pen_dst = smem + (lane < K ? Lds::PV + lane : Lds::PART + 2 * lane);      // (the scratch of the matrices again: stored later, read never)
@@ -405,11 +435,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #endif
         for (int it = 0; it < iters; it++) {
             {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
-                const float* tot = smem + Lds::TOT + 3 * (is_qubit ? lane : 0);
+                const float* tot = smem + Lds::TOT + 3 * qa;
                 float gs[3] = {0.f, 0.f, 0.f};
                 if (it > 0) zyz::chain_surface(gs, tot[0], tot[1], tot[2], my_flip != 0.f ? 1 : 0, cs[1][0], cs[1][1], cs[2][0], cs[2][1]);
-                g01 = f2{gs[0], gs[1]}; g23 = f2{gs[2], 0.f};
-                adam_sincos(it);
+                const float g2 = z3_nb(gs[2]);              // the third angle's gradient, for the odd lane
+                g01 = (lane & 1) ? f2{g2, 0.f} : f2{gs[0], gs[1]};
+                adam_sincos(it, ic<1>{}, splat(0.5f));
                 publish_surface();
                 if (ENT == 0 && a.use_reg) {
                     // the penalty of CP angle `lane` (penalty.py:44-71): its value for the loss, its slope for wave B's next Adam step.
@@ -441,7 +472,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 constexpr int B = decltype(bb)::value;
                 ent[B] = *reinterpret_cast<const float4*>(tab + 16 * B + kofs[B % LL]);
             }, typename make_iseq<M>::type{});
-            my_flip = lane == 0 ? msf.x : (lane == 1 ? msf.y : msf.z);
+            my_flip = qa == 0 ? msf.x : (qa == 1 ? msf.y : msf.z);
             const f2 f0 = msf.x != 0.f ? f2{fb[0].x, fb[0].y} : f2{fa[0].x, fa[0].y};
             const f2 f1 = msf.y != 0.f ? f2{fb[1].x, fb[1].y} : f2{fa[1].x, fa[1].y};
             const f2 f2_ = msf.z != 0.f ? f2{fb[2].x, fb[2].y} : f2{fa[2].x, fa[2].y};
@@ -535,24 +566,39 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     int lastside[3] = {-1, -1, -1}, firstside[3] = {-1, -1, -1};
     for (int w = 2 * K - 1; w >= 0; w--) firstside[qubit_of(w)] = w;
     for (int w = 0; w < 2 * K; w++) lastside[qubit_of(w)] = w;
-    const bool is_side = owner_wave && il < 2 * K;
-    const int ib = il >> 1, iside = il & 1;
-    int prev = -1, prev_dn = -1;                             // previous side on the side's qubit (even lanes: also of the block's dn side)
+    // S2: lanes 2 w and 2 w + 1 work for side w - the even one is its main lane (slots 0, 1 and everything else), the odd one owns slots 2, 3
+    const int iw = S2 ? (il >> 1) : il;
+    const bool odd2 = S2 && (il & 1);
+    const bool is_owner = owner_wave && il < NITEM;          // a lane with angles of a side
+    const bool is_side = is_owner && !odd2;                  // the side's main lane
+    const int ib = iw >> 1, iside = iw & 1;
+    int prev = -1, prev_dn = -1;                             // previous side on the side's qubit (side 0: also of the block's dn side)
     unsigned long long later = 0;                            // later sides on the side's qubit
     int first_q = -1;                                        // the qubit this side is the first one on (it publishes the qubit's flip parity)
     if (is_side) {
-        const int q = qubit_of(il);
-        for (int w = il - 1; w >= 0; w--) if (qubit_of(w) == q) { prev = w; break; }
-        for (int w = il + 1; w < 2 * K; w++) if (qubit_of(w) == q) later |= 1ull << (lane0 + w);          // bit = the lane that owns the side
-        if (iside == 0) { const int qd = qubit_of(il + 1); for (int w = il - 1; w >= 0; w--) if (qubit_of(w) == qd) { prev_dn = w; break; } }
+        const int q = qubit_of(iw);
+        for (int w = iw - 1; w >= 0; w--) if (qubit_of(w) == q) { prev = w; break; }
+        for (int w = iw + 1; w < 2 * K; w++) if (qubit_of(w) == q) later |= 1ull << (lane0 + (S2 ? 2 * w : w));   // bit = the main lane of the side
+        if (iside == 0) { const int qd = qubit_of(iw + 1); for (int w = iw - 1; w >= 0; w--) if (qubit_of(w) == qd) { prev_dn = w; break; } }
 #pragma unroll
-        for (int k = 0; k < NR; k++) pj[k] = NS + NBP * ib + 2 * k + iside;
-        if (ENT == 0 && iside == 0) pj[3] = NS + NBP * ib + 2 * NR;
+        for (int q = 0; q < 3; q++) if (firstside[q] == iw) first_q = q;
+    }
+    if (is_owner) {                                          // global slot k: rotation letter k of the side; slot 3: the block's CP angle (side 0)
 #pragma unroll
-        for (int q = 0; q < 3; q++) if (firstside[q] == il) first_q = q;
+        for (int k = 0; k < 4; k++) {
+            const int j = k < NR ? NS + NBP * ib + 2 * k + iside : ((k == 3 && ENT == 0 && iside == 0) ? NS + NBP * ib + 2 * NR : -1);
+            if (!S2) pj[k] = j;
+            else if ((k >> 1) == (odd2 ? 1 : 0)) pj[k & 1] = j;
+        }
     }
     load_angles(os_idx, ovs);
-    const bool has_cp = ENT == 0 && is_side && iside == 0;
+    const bool has_cp = ENT == 0 && is_owner && iside == 0 && (!S2 || odd2);       // the lane that holds the CP angle: slot 3, or slot 1 of the odd lane
+    const f2 sc01 = (S2 && odd2) ? f2{0.5f, 1.f} : f2{0.5f, 0.5f};
+    auto cp_angle = [&]() __attribute__((always_inline)) { return S2 ? th01.y : th23.y; };
+    // the value held by the main lane of the block's other side
+    auto side_nb = [&](auto v) __attribute__((always_inline)) {
+        if constexpr (S2) return z3_partner<1>(v); else return z3_nb(v);
+    };
     zyz::Side sd = zyz::Side{};
     int cacb = 0;                                            // even side lanes: where the entangler's phase sits
     float psl = 0.f;
@@ -562,8 +608,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         rowP = Lds::row_blk(ib) + 3 * iside;
         row_s11 = ib == 0 ? 9 : Lds::row_blk(ib - 1) + 6;
         auto pz_row = [&](int pw, int w) { return pw >= 0 ? Lds::row_blk(pw >> 1) + 3 * (pw & 1) + 2 : 3 * qubit_of(w) + 2; };   // Pz of the previous side, or of the surface state
-        row_pzu = pz_row(prev, il);
-        row_pzd = iside == 0 ? pz_row(prev_dn, il + 1) : 0;
+        row_pzu = pz_row(prev, iw);
+        row_pzd = iside == 0 ? pz_row(prev_dn, iw + 1) : 0;
     }
     const int prev_off = Lds::REC1 + 4 * (prev >= 0 ? prev : 2 * K);
     // final left factors: the last side on each row qubit, read at the start of every step
@@ -582,10 +628,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     for (int it = 0; it < iters; it++) {
         // ================= owner: Adam closes the previous step; (cos, sin); sides, parities, e-pairs, tables, surface matrices
         if (owner_wave) {
-        if (it > 0 && has_cp && a.use_reg) g23.y += psl;
-        adam_sincos(it);
+        if (it > 0 && has_cp && a.use_reg) { if constexpr (S2) g01.y += psl; else g23.y += psl; }
+        adam_sincos(it, ic<S2 ? 1 : 0>{}, sc01);
         if (ENT == 0 && a.use_reg) {                          // wave A evaluates the penalty of the CP angles: the angles, then the step counter it waits for
-            if (has_cp) osmem[Lds::PTH + ib] = th23.y;
+            if (has_cp) osmem[Lds::PTH + ib] = cp_angle();
             lds_fence();
             if (il == 0) osmem[Lds::MSF + 3] = (float)(it + 1);
         }
@@ -595,7 +641,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 c = cs[k][0]; sn = cs[k][1]; kind = 0;
             };
             sd = zyz::side_build<ROT & 0xFFFF>(rrec, NR, iside);
-            if (is_side) *reinterpret_cast<float4*>(osmem + Lds::REC1 + 4 * il) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
+            if (is_side) *reinterpret_cast<float4*>(osmem + Lds::REC1 + 4 * iw) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
             const unsigned long long fbits = __builtin_amdgcn_ballot_w64(is_side && sd.f != 0);
             sd.m = __popcll(fbits & later) & 1;
             if (first_q >= 0) osmem[Lds::MSF + first_q] = (float)(sd.m ^ sd.f);      // every flip on the qubit: those later than its first side, and that side's own
@@ -604,10 +650,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             const zyz::EPair e = zyz::side_epair(sd, true, zyz::c2(pl.x, pl.y), zyz::c2(pl.z, pl.w));      // "no previous side" reads the identity record
             // the block's other side is the neighbouring lane: exchange the e-pairs instead of a trip through LDS, then this lane
             // builds the two entries with a_up = iside (side 0: entries (0, 0), (0, 1); side 1: (1, 0), (1, 1))
-            const f2 pe0 = {z3_nb(e.e0.re), z3_nb(e.e0.im)}, pe1 = {z3_nb(e.e1.re), z3_nb(e.e1.im)};
-            const int pc = z3_nb(e.c);
-            const float psc = z3_nb(sd.sc), pt = z3_nb(sd.t);
-            const float plc = z3_nb(cs[3][0]), pls = z3_nb(cs[3][1]);          // the CP angle belongs to side 0
+            const f2 pe0 = {side_nb(e.e0.re), side_nb(e.e0.im)}, pe1 = {side_nb(e.e1.re), side_nb(e.e1.im)};
+            const int pc = side_nb(e.c);
+            const float psc = side_nb(sd.sc), pt = side_nb(sd.t);
+            const float plc = side_nb(cs[3][0]), pls = side_nb(cs[3][1]);          // the CP angle belongs to side 0
             const f2 lam = ENT != 0 ? f2{-1.f, 0.f} : (iside ? f2{plc, pls} : f2{cs[3][0], cs[3][1]});
             const f2 my0 = {e.e0.re, e.e0.im}, my1 = {e.e1.re, e.e1.im};
             const f2 X = iside ? pe1 : my0, Y0 = iside ? my0 : pe0, Y1 = iside ? my1 : pe1;
@@ -722,7 +768,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             float gp[4] = {0.f, 0.f, 0.f, 0.f};
             zyz::chain_side<ROT & 0xFFFF>(gp, px, py, pz, sd, rrec, NR, iside);
             if (ENT == 0) gp[3] = zyz::chain_cp(s11, pzu, pzd, cacb, 1.f);
-            g01 = f2{gp[0], gp[1]}; g23 = f2{gp[2], gp[3]};
+            if constexpr (S2) {                           // slots 2, 3 go to the odd lane beside the main lane
+                const float n2 = z3_nb(gp[2]), n3 = z3_nb(gp[3]);
+                g01 = odd2 ? f2{n2, n3} : f2{gp[0], gp[1]};
+            } else { g01 = f2{gp[0], gp[1]}; g23 = f2{gp[2], gp[3]}; }
         }
         CPF_STAMP(7)
     }
@@ -735,7 +784,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         const int bi = (best < first) ? 1 : 0;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
-            const int j = pj[3];
+            const int j = S2 ? pj[1] : pj[3];
             const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = a.out_params[(os_idx * 2 + 1) * P + j];
             float sl;
             if (a.use_reg) { acc0 = penalty_lds(osmem, a.pen_kind, t0, sl); acc1 = penalty_lds(osmem, a.pen_kind, t1, sl); }

@@ -768,20 +768,22 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 // ---- two-ended ZYZ form, 3 qubits (cpf_zyz3.h): block count, cut, samples per workgroup and layer are compile-time constants of
 // every instance.  The cut M = blocks swept by wave A, which also owns the surface gates and the penalty; wave B owns the blocks'
 // angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named; profiles/r05_cfg2_levers_ab.txt):
-//   one sample per CU      256 samples: 4.32 / 4.08 / 4.07 at 4 / 5 / 6; 100 samples of 14 blocks 4.40 / 4.24 / 4.23 at 5 / 6 / 7, of
-//                          24 blocks 5.71 / 5.63 / 5.61 at 10 / 11 / 12                                  -> (K - 1) / 2
-//   two per CU             512: 4.70 at 4; with both samples in ONE workgroup (the hardware starts two-wave workgroups one SIMD
-//                          apart, which books a SIMD twice at two per CU) 4.42 / 4.35 at 5 / 6           -> K / 2, pairs
-//   more, all resident     1024: 4.65 / 4.68 at 3 / 4 (4.90 at 5); 1536: 6.42 / 6.52 / 6.51 at 3 / 4 / 5; config 3's shape (16 blocks) 512: 5.16 / 5.21 / 5.32 at 5 / 6 / 7;
-//                          1000 samples of 8 CZ blocks 4.02 / 4.19 at 2 / 3                              -> 0.33 K
-//   in rounds              2048: 10.16 / 10.22 / 11.09 at 4 / 5 / 6; 4096: 22.70 / 21.75 (both at six resident per CU);
-//                          config 3's shape 4096: 23.2 / 22.6 at 6 / 7                                   -> 0.43 K
+//   one sample per CU      256 samples: 4.12 / 3.93 / 3.80 at 4 / 5 / 6; 100 samples of 14 blocks 4.39 / 4.12 / 4.11 at 5 / 6 / 7
+//                                                                                                        -> K / 2
+//   more, all resident     1024: 4.48 / 4.37 / 4.46 / 4.57 at 2 / 3 / 4 / 5; 512: 4.28 / 4.35 / 4.51 at 3 / 4 / 5; config 3's shape
+//                          (16 blocks) 512: 4.89 / 4.77 / 4.93 at 4 / 5 / 6                              -> 0.33 K
+//   in rounds              2048: 10.72 / 10.54 at 4 / 5; (before the two-lane owner layout) 4096: 22.70 / 21.75 at 4 / 5, config 3's
+//                          shape 4096: 23.2 / 22.6 at 6 / 7                                              -> 0.43 K
+// Two samples per workgroup sharing the owner of the block angles (PAIRS = 2) paid at two samples per CU while an owner lane carried
+// all four angle slots of its side (4.35 against 4.70 ms); with two lanes per side (cpf_zyz3.h S2, one sample per workgroup only) it
+// loses (4.46 against 4.28) and is a switch only.
 // CPF_ZYZ3_M overrides the cut, CPF_ZYZ3_PAIRS the samples per workgroup, CPF_ZYZ3_RES the workgroups resident per CU.
 int64_t zyz3_per_cu(const cpf_plan* plan, int64_t S) { return (S + plan->num_cu - 1) / plan->num_cu; }
 int64_t zyz3_max_resident(const cpf_plan* plan) { return std::min<int64_t>(16, plan->lds_per_cu / ((int64_t)cpf::zyz3_lds_floats(plan->K) * 4)); }
 bool zyz3_all_resident(const cpf_plan* plan, int64_t S) { return zyz3_per_cu(plan, S) <= zyz3_max_resident(plan); }
 int zyz3_pairs(const cpf_plan* plan, int64_t S) {
-    int pairs = (plan->K <= 14 && zyz3_per_cu(plan, S) == 2) ? 2 : 1;      // 16 blocks: measured level with one sample per workgroup
+    (void)S;
+    int pairs = 1;
     { const TuneVal e = tuning("CPF_ZYZ3_PAIRS"); if (e) pairs = (e[0] == '2' && 2 * plan->K <= 32) ? 2 : 1; }
     if ((int64_t)2 * cpf::zyz3_lds_floats(plan->K) * 4 > plan->lds_per_cu) pairs = 1;
     return pairs;
@@ -789,7 +791,7 @@ int zyz3_pairs(const cpf_plan* plan, int64_t S) {
 int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
     const int64_t per_cu = zyz3_per_cu(plan, S);
-    int m = per_cu <= 1 ? (K - 1) / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K) / 100 : (43 * K + 50) / 100));
+    int m = per_cu <= 1 ? K / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K) / 100 : (43 * K + 50) / 100));
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }

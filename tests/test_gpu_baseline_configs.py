@@ -68,7 +68,7 @@ def test_config3_toffoli_all_to_all_at_size():
     whole 4096 on one GPU, 2000 iterations; plus short-run oracle parity on the same target."""
     from cpflow_amd import workloads
     wl = workloads.CONFIGS['cfg3']
-    assert _short_run_parity(wl, S=5, T=14, tol=1e-5) == 'zyz3/aot waves=2 K cut=7'
+    assert _short_run_parity(wl, S=5, T=14, tol=1e-5) == 'zyz3/aot waves=2 K cut=8'
     eng = _engine(wl)
     stats = []
     for S, first in ((512, 1024), (4096, 0)):          # rank 2's block of the 8-GPU run; all samples on one GPU

@@ -397,7 +397,7 @@ def _score(cz_passed, S):
 T3_MORE = [
     # G3, 3 qubits all-to-all, 200 samples: 198 stored; float32 / float64 oracle: 199 passes, all 198 stored ones among them.
     # Its stored reg values come from older penalty constants, which moves a few CZ counts, not the pass set
-    ('raw_toff3_conn_t99', 'zyz3/jit(hipcc) waves=2 K cut=4', 3, 195, 14, 0.15),             # 10 blocks: a shipped K-specialised kernel
+    ('raw_toff3_conn_t99', 'zyz3/jit(hipcc) waves=2 K cut=5', 3, 195, 14, 0.15),             # 10 blocks: a shipped K-specialised kernel
     # G2 trial 49, 4-qubit star, 500 samples, 7 stored passes (the oracle finds the same 7)
     ('raw_toff4_star_t49', 'zyzl/jit(hipcc)', 4, 5, 4, 1.6),                 # 500 samples: one wave per sample, the ZYZ form
     # G5, 5-qubit chain 'xyz', 86 blocks, 1000 samples, 39 stored passes.  The stored run used OLDER penalty constants (its

@@ -6,20 +6,19 @@ NUM_CU, LDS_PER_CU = 256, 160 * 1024
 
 
 def lds_bytes(K):
-    rows, up4 = 10 + 7 * K, lambda x: (x + 3) & ~3
+    rows, srows, up4 = 10 + 7 * K, 7 + 5 * K, lambda x: (x + 3) & ~3
     tot = 28 + 8 * K + 4 + 3 * up4(K) + 16 * K + 48 + 4
-    return 4 * (up4(tot + rows) + 2 * 128 + rows * 68)
+    return 4 * (up4(tot + rows + 1) + 2 * 128 + srows * 68)
 
 
 def pairs(K, S):
-    per_cu = -(-S // NUM_CU)
-    return 2 if (K <= 14 and per_cu == 2 and 2 * lds_bytes(K) <= LDS_PER_CU) else 1
+    return 1          # two samples per workgroup: a switch only since the two-lane owner layout (cpflow_amd.hip zyz3_pairs)
 
 
 def cut(K, S):
     per_cu, fit = -(-S // NUM_CU), min(16, LDS_PER_CU // lds_bytes(K))
     if per_cu <= 1:
-        m = (K - 1) // 2
+        m = K // 2
     elif pairs(K, S) == 2:
         m = K // 2
     elif per_cu <= fit:
