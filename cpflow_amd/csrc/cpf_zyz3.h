@@ -366,13 +366,16 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }
     };
     // loss and best-iterate tracking from T and the penalty values of the lane's sample (both waves: the same instructions on the same numbers)
-    auto track = [&](int it, float tr, float ti, const float4 (&pvq)[(K + 3) / 4], int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
+    // r x the sum of the K penalty values (both waves: the same additions in the same order)
+    auto pen_reg = [&](const float4 (&pvq)[(K + 3) / 4]) __attribute__((always_inline)) {
         float pen_sum = 0.f;
         if (a.use_reg) {
 #pragma unroll
             for (int k = 0; k < (K + 3) / 4; k++) pen_sum += (pvq[k].x + pvq[k].y) + (pvq[k].z + pvq[k].w);
         }
-        const float reg = a.use_reg ? a.r * pen_sum : 0.f;
+        return a.use_reg ? a.r * pen_sum : 0.f;
+    };
+    auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
         const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
         const float regloss = loss + reg;
         bool improved = false;
@@ -486,19 +489,21 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 own[B + 1] = x;
             }, typename make_iseq<M>::type{});
             sp[0] = x;                                       // psi(s_{M-1}): the only state the other wave reads
+            // This wave's forward and gradient halves are the shorter ones (wave B owns nothing but sweeps more blocks), its owner and
+            // loss phases the longer ones: the penalty sum (its values are this wave's own, from before the last barrier) is formed
+            // here and the best-iterate tracking waits until the gradient half is done - both in time the wave would spend waiting.
+#pragma unroll
+            for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(smem + Lds::PV)[k];
+            const float reg_a = pen_reg(pvq);
             CPF_STAMP(2)                                  // forward half
             barrier();
             CPF_STAMP(3)
             const f2 w_c = sp[64];
-#pragma unroll
-            for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(smem + Lds::PV)[k];
             const f2 tt = z3_cmul_conj(w_c, x);              // T = sum conj(W) psi at the cut
             float tr = tt.x, ti = tt.y;
             z3_allsum(tr, ti, odd);
             f2 w = z3_cmul(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, w_c);       // the cotangent at the cut: f W, f = -T / N^2
-            track(it, tr, ti, pvq, s_idx, live, false);
-            if (a.T == 0) break;
-            if (it + 1 == iters) break;
+            if (a.T == 0 || it + 1 == iters) { track(it, tr, ti, reg_a, s_idx, live, false); break; }
             CPF_STAMP(4)                                  // loss
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = M - 1 - decltype(bb)::value, J = B % LL;
@@ -533,6 +538,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             lds_fence();
 #pragma unroll
             for (int r = 0; r < NRA; r++) row_sums(rka[r]);
+            track(it, tr, ti, reg_a, s_idx, live, false);
             CPF_STAMP(5)                                  // gradient half + row sums
             barrier();
             CPF_STAMP(6)
@@ -722,7 +728,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 z3_allsum(tr1, ti1, odd);
                 otr = upper ? tr1 : tr; oti = upper ? ti1 : ti;
             }
-            track(it, otr, oti, pvq, os_idx, ovs, il == 0);
+            track(it, otr, oti, pen_reg(pvq), os_idx, ovs, il == 0);
         }
         if (a.T == 0) break;
         if (it + 1 == iters) break;                   // the last step's gradient would move the angles past the last evaluated iterate
