@@ -770,8 +770,8 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 // angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named; profiles/r05_cfg2_levers_ab.txt):
 //   one sample per CU      256 samples: 4.12 / 3.93 / 3.80 at 4 / 5 / 6; 100 samples of 14 blocks 4.39 / 4.12 / 4.11 at 5 / 6 / 7
 //                                                                                                        -> K / 2
-//   more, all resident     1024: 4.48 / 4.37 / 4.46 / 4.57 at 2 / 3 / 4 / 5; 512: 4.28 / 4.35 / 4.51 at 3 / 4 / 5; config 3's shape
-//                          (16 blocks) 512: 4.89 / 4.77 / 4.93 at 4 / 5 / 6                              -> 0.33 K
+//   more, all resident     1024: 4.31 / 4.23 at 3 / 4 (before wave A's tracking moved behind its gradient half: 4.48 / 4.37 / 4.46 /
+//                          4.57 at 2 / 3 / 4 / 5); config 3's shape (16 blocks) 512: 4.66 / 4.71 at 5 / 6     -> 0.33 K, rounded
 //   in rounds              2048: 10.72 / 10.54 at 4 / 5; (before the two-lane owner layout) 4096: 22.70 / 21.75 at 4 / 5, config 3's
 //                          shape 4096: 23.2 / 22.6 at 6 / 7                                              -> 0.43 K
 // Two samples per workgroup sharing the owner of the block angles (PAIRS = 2) paid at two samples per CU while an owner lane carried
@@ -791,7 +791,7 @@ int zyz3_pairs(const cpf_plan* plan, int64_t S) {
 int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
     const int64_t per_cu = zyz3_per_cu(plan, S);
-    int m = per_cu <= 1 ? K / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K) / 100 : (43 * K + 50) / 100));
+    int m = per_cu <= 1 ? K / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K + 50) / 100 : (43 * K + 50) / 100));
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }

@@ -275,7 +275,7 @@ def test_fixed_entangler_templates_match_oracle(ent, layer, K, rot):
 
 @pytest.mark.parametrize('ent,layer,K,rot,S,kind', [
     ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 5, 'zyz3/jit'), ('cz', [[0, 1], [0, 2], [1, 2]], 14, 'xyz', 3000, 'zyz3/jit(hipcc) waves=2 K cut=6'),
-    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=2'),        # the local-minimum study's shape: shipped
+    ('cz', [[0, 1], [0, 2], [1, 2]], 8, 'xyz', 1000, 'zyz3/jit(hipcc) waves=2 K cut=3'),        # the local-minimum study's shape: shipped
     ('cz', [[0, 1], [0, 2], [1, 2]], 15, 'xyz', 3000, 'zyz3/jit'),                               # a block count nobody shipped, SIMDs full
     ('cz', [[0, 1], [1, 2]], 3, 'xyz', 4, 'zyz3/jit'), ('cz', [[1, 2], [0, 1]], 9, 'xz', 6, 'zyz3/jit'),
     ('cz', [[0, 1], [1, 2], [2, 3]], 7, 'xyz', 3, 'layered/jit'), ('cz', [[0, 1], [0, 2], [0, 3], [0, 4]], 9, 'yz', 2, 'zyzl/jit'),

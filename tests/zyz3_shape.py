@@ -22,7 +22,7 @@ def cut(K, S):
     elif pairs(K, S) == 2:
         m = K // 2
     elif per_cu <= fit:
-        m = (33 * K) // 100
+        m = (33 * K + 50) // 100
     else:
         m = (43 * K + 50) // 100
     return max(1, min(K - 1, m))
