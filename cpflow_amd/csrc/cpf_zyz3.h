@@ -160,7 +160,29 @@ __device__ __forceinline__ void z3_allsum(float& re, float& im, bool odd) {
     const z3_f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? i1 : r1, 1.0f, zero, 0, 0, 0);
     re = d2[0]; im = d2[1];
 #else
-    wave_sum2(re, im);
+    // cpf_device.h wave_sum2 with its two row_bcast stages as ONE v_add_f32_dpp each under a row mask (the compiler builds them from a
+    // zeroed register, a v_mov_b32_dpp and an add, with two wait states in front: 8 instructions more per call)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(re), "+v"(im));
+    re = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(re), 63));
+    im = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(im), 63));
 #endif
 }
 // three sums at once, stages interleaved (each fills the others' DPP wait states)
