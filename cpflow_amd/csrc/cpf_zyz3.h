@@ -397,17 +397,24 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }
         return a.use_reg ? a.r * pen_sum : 0.f;
     };
-    auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
-        const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
-        const float regloss = loss + reg;
-        bool improved = false;
-        if (it == 0) { first = regloss; best = regloss; }
-        else if (regloss < best) { best = regloss; improved = true; }
-        const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
-        if (improved && live) {
+    // The best iterate's angles stay in registers (selects, no branch and no store inside the step) and are written once, by
+    // store_best, after the last step.
+    f2 bt01 = {0.f, 0.f}, bt23 = {0.f, 0.f};
+    auto store_best = [&](int64_t sample, bool live) __attribute__((always_inline)) {
+        const float t0[4] = {bt01.x, bt01.y, bt23.x, bt23.y};
+        if (live) {
 #pragma unroll
             for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.out_params[(sample * 2 + 1) * P + pj[k]] = t0[k];
         }
+    };
+    auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
+        const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
+        const float regloss = loss + reg;
+        const bool take = it == 0 || regloss < best;         // strict: the first of equal losses stays (optimization.py:365-370 argmin)
+        first = it == 0 ? regloss : first;
+        best = take ? regloss : best;
+        bt01 = take ? th01 : bt01; bt23 = take ? th23 : bt23;
+        const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
 #ifndef CPF_STAMPS
         if (a.hist_params && live) {
 #pragma unroll
@@ -569,6 +576,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
 #endif
+        store_best(s_idx, live);
         return;
     }
 
@@ -809,11 +817,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 
     // ---- epilogue (optimization.py:365-370, cp_utils.py:144-164): reg recompute, loss = regloss - reg, argmin, CZ count, entry-loss flag
     if (owner_wave) {
+        store_best(os_idx, ovs);
         const int bi = (best < first) ? 1 : 0;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
             const int j = S2 ? pj[1] : pj[3];
-            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = a.out_params[(os_idx * 2 + 1) * P + j];
+            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = S2 ? bt01.y : bt23.y;      // the initial CP angle (stored by the set-up), the best one
             float sl;
             if (a.use_reg) { acc0 = penalty_lds(osmem, a.pen_kind, t0, sl); acc1 = penalty_lds(osmem, a.pen_kind, t1, sl); }
             acc2 = cz_value(bi ? t1 : t0, a.thr_cp);
