@@ -338,15 +338,29 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     f2 g01 = {0.f, 0.f}, g23 = {0.f, 0.f}, nlr01 = {0.f, 0.f}, nlr23 = {0.f, 0.f};
     float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
     float best = 0.f, first = 0.f;
-    auto load_angles = [&](int64_t sample, bool live) __attribute__((always_inline)) {
+    // HBM is touched at the two ends of the run only, and in whole rows: the pair's 128 threads read the sample's P initial angles
+    // contiguously into LDS (the rows of shares: free until the first gradient half) and copy them to both output slots; an owner lane
+    // takes its angles from there, and after the last step puts its best ones back for one contiguous store (scattered 4-byte
+    // accesses of the owner lanes cost four times the bytes in 32- / 64-byte sectors: 3.15 MB per launch of config 2 against 0.79).
+    static_assert(Lds::SROWS * ZYZ3_ROW >= 9 + 7 * K, "the angles of a sample fit the scratch");
+    {
+        const bool live_pair = PAIRS == 1 || s_raw < a.nsamples;
+        float* const ang = smem + Lds::PART;
+        for (int j = tid; j < P; j += 128) {
+            const float v = a.init[s_idx * P + j];
+            ang[j] = v;
+            if (live_pair) { a.out_params[(s_idx * 2) * P + j] = v; a.out_params[(s_idx * 2 + 1) * P + j] = v; }
+        }
+        barrier();
+    }
+    auto load_angles = [&](const float* ang, int64_t sample) __attribute__((always_inline)) {
         float t0[4], nl[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             t0[k] = 0.f; nl[k] = 0.f;
             if (pj[k] >= 0) {
-                t0[k] = a.init[sample * P + pj[k]];
+                t0[k] = ang[pj[k]];
                 nl[k] = (a.frozen && a.frozen[sample * P + pj[k]]) ? 0.f : -a.lr;
-                if (live) { a.out_params[(sample * 2) * P + pj[k]] = t0[k]; a.out_params[(sample * 2 + 1) * P + pj[k]] = t0[k]; }
             }
         }
         th01 = f2{t0[0], t0[1]}; th23 = f2{t0[2], t0[3]}; nlr01 = f2{nl[0], nl[1]}; nlr23 = f2{nl[2], nl[3]};
@@ -400,12 +414,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // The best iterate's angles stay in registers (selects, no branch and no store inside the step) and are written once, by
     // store_best, after the last step.
     f2 bt01 = {0.f, 0.f}, bt23 = {0.f, 0.f};
-    auto store_best = [&](int64_t sample, bool live) __attribute__((always_inline)) {
+    auto put_best = [&](float* ang) __attribute__((always_inline)) {          // the owner lane's best angles, back into the sample's row in LDS
         const float t0[4] = {bt01.x, bt01.y, bt23.x, bt23.y};
-        if (live) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.out_params[(sample * 2 + 1) * P + pj[k]] = t0[k];
-        }
+        for (int k = 0; k < 4; k++) if (pj[k] >= 0) ang[pj[k]] = t0[k];
     };
     auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
         const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
@@ -439,7 +451,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         const bool is_qubit = lane < 6 && !(lane & 1);     // the main lane of qubit lane >> 1; the odd lane beside it owns the third angle
         const int qa = lane < 6 ? lane >> 1 : 0;
         if (lane < 6) { if (lane & 1) pj[0] = 3 * qa + 2; else { pj[0] = 3 * qa; pj[1] = 3 * qa + 1; } }
-        load_angles(s_idx, live);
+        load_angles(smem + Lds::PART, s_idx);
         float my_flip = 0.f;
         // No branch on the lane here: every lane forms a matrix and stores it, the lanes that own no qubit into the rows of shares
         // (dead between the last barrier of a step and the gradient halves of the next).  A divergent region next to the loop's back
@@ -576,7 +588,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
 #endif
-        store_best(s_idx, live);
+        put_best(smem + Lds::PART);
+        barrier();                                           // wave B of the pair stores the row
         return;
     }
 
@@ -627,7 +640,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             else if ((k >> 1) == (odd2 ? 1 : 0)) pj[k & 1] = j;
         }
     }
-    load_angles(os_idx, ovs);
+    load_angles(osmem + Lds::PART, os_idx);
     const bool has_cp = ENT == 0 && is_owner && iside == 0 && (!S2 || odd2);       // the lane that holds the CP angle: slot 3, or slot 1 of the odd lane
     const f2 sc01 = (S2 && odd2) ? f2{0.5f, 1.f} : f2{0.5f, 0.5f};
     auto cp_angle = [&]() __attribute__((always_inline)) { return S2 ? th01.y : th23.y; };
@@ -816,8 +829,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #endif
 
     // ---- epilogue (optimization.py:365-370, cp_utils.py:144-164): reg recompute, loss = regloss - reg, argmin, CZ count, entry-loss flag
+    if (owner_wave) put_best(osmem + Lds::PART);
+    barrier();
+    if (PAIRS == 1 || s_raw < a.nsamples) {
+        const float* ang = smem + Lds::PART;
+        for (int j = lane; j < P; j += 64) a.out_params[(s_idx * 2 + 1) * P + j] = ang[j];
+    }
     if (owner_wave) {
-        store_best(os_idx, ovs);
         const int bi = (best < first) ? 1 : 0;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
