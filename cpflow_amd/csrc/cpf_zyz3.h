@@ -340,8 +340,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     float best = 0.f, first = 0.f;
     // HBM is touched at the two ends of the run only, and in whole rows: the pair's 128 threads read the sample's P initial angles
     // contiguously into LDS (the rows of shares: free until the first gradient half) and copy them to both output slots; an owner lane
-    // takes its angles from there, and after the last step puts its best ones back for one contiguous store (scattered 4-byte
-    // accesses of the owner lanes cost four times the bytes in 32- / 64-byte sectors: 3.15 MB per launch of config 2 against 0.79).
+    // takes its angles from there, and after the last step puts its best ones back for one contiguous store (instead of scattered
+    // 4-byte accesses of the owner lanes; time-neutral, 4.37 / 4.33 ms).
     static_assert(Lds::SROWS * ZYZ3_ROW >= 9 + 7 * K, "the angles of a sample fit the scratch");
     {
         const bool live_pair = PAIRS == 1 || s_raw < a.nsamples;
