@@ -61,6 +61,7 @@ struct KArgs {
     const uint8_t* pkind;      // [P] 1 = CP angle (full angle, penalised), 0 = rotation (half angle)
     const int32_t* pgate;      // [P] index of the gate that carries angle j
     const float2* bias;        // [T] {1 - b1^t, 1 - b2^t}, t = 1..T
+    const float2* ibias;       // [T] their reciprocals in float32 (cpf_zyz3.h: two v_rcp_f32 fewer per wave and step)
     Piece pc[10];
     int pen_kind, use_reg;
     int loss_kind;             // 0 HST / state preparation (|T|^2 form, scale in inv_dim2), 2 relative phase

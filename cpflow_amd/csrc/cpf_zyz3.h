@@ -64,12 +64,13 @@
 
 namespace cpf {
 
+typedef __attribute__((address_space(3))) float z3_lds_f;     // a float in LDS (32-bit pointers: what the per-block store bases are kept as)
 constexpr int ZYZ3_ROW = 68;                     // floats per row of shares: 64 lanes + 4 (16 lanes of one ds_read_b128 pass hit 16 different bank groups)
 
 // floats of LDS per sample of an instance with K blocks (Zyz3Lds<K>::TOTAL)
 __host__ __device__ constexpr int zyz3_lds_floats(int K) {
     const int rows = 10 + 7 * K, srows = 7 + 5 * K;
-    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 4, states = (tot + rows + 1 + 3) & ~3;
+    const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 24, states = (tot + rows + 1 + 3) & ~3;
     return states + 128 * 2 + srows * ZYZ3_ROW;
 }
 __host__ __device__ constexpr bool zyz3_supported(int K, int n_rot) { return K >= 2 && 2 * K <= 64 && n_rot >= 1 && n_rot <= 3; }
@@ -85,8 +86,11 @@ struct Zyz3Lds {                                  // float offsets, per sample; 
     static constexpr int PSL = PTH + up4(K);      // r x the penalty's slope at each of them (wave A -> wave B's next Adam step)
     static constexpr int TAB = PSL + up4(K);      // K x 4 entries x {d.re, d.im, t_up signed, t_dn signed}
     static constexpr int SURFM = TAB + 16 * K;    // 3 x {S, F S} x 2x2 complex: both variants of each surface matrix
-    static constexpr int MSF = SURFM + 48;        // the three flip parities (floats 0 / 1), one spare
-    static constexpr int TOT = MSF + 4;           // the ROWS sums, one spare slot behind them for stores that mean nothing
+    static constexpr int MSF = SURFM + 48;        // the three flip parities (floats 0 / 1); [3] the step counter wave A waits for;
+                                                  // [4] "this step's iterate is the best so far" (wave B decides, wave A follows); 3 spare
+                                                  // [5], [6] the barrier counts of the sample's waves A and B (compared after the last step)
+    static constexpr int CPT = MSF + 8;           // 4 x {k_t, k_u, k_d, -}: the CP angle's chain rule by (ca | cb << 1) (zyz::chain_cp as a table)
+    static constexpr int TOT = CPT + 16;          // the ROWS sums, one spare slot behind them for stores that mean nothing
     static constexpr int STATES = up4(TOT + ROWS + 1);       // 2 x 64 x (re, im): the two states at the cut, psi(s_{M-1}) and W(s_{M-1})
     static constexpr int PART = STATES + 128 * 2;            // SROWS x ZYZ3_ROW
     static constexpr int TOTAL = PART + SROWS * ZYZ3_ROW;
@@ -108,6 +112,13 @@ __device__ __forceinline__ f2 z3_cmul_conj(f2 d, f2 x) {
         "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=&v"(o) : "v"(d), "v"(x));
     return o;
 }
+// conj(d) * x twice: o stays (the state the gradient half reads), w is what the next block's in-place stages overwrite - one
+// packed instruction more instead of the two v_mov_b32 a copy costs, and one link less in the sweep's dependent chain
+__device__ __forceinline__ void z3_cmul_conj2(f2 d, f2 x, f2& o, f2& w) {
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=&v"(o), "=&v"(w) : "v"(d), "v"(x));
+}
 // One real stage on row qubit Q: x <- x + t x[partner] (NEG: - t), t signed for this lane: two v_fmac_f32_dpp whose DPP operand is
 // the destination itself (the compiler does not fold a DPP read into an accumulate onto the register it reads: it emitted
 // v_mov_b32_dpp + v_fma_f32, six issue slots per stage instead of four).  quad_perm / row_ror move within a row of 16 lanes, which
@@ -125,6 +136,141 @@ __device__ __forceinline__ void z3_stage(f2& x, float t) {
     else { CPF_Z3_STAGE("row_ror:8") }
 }
 #undef CPF_Z3_STAGE
+// Both stages of a block in ONE statement: first on row qubit QA, then on QB.  (Between two asm statements the compiler puts a wait
+// state of its own: it cannot see what the first one wrote.)  Wait states: two between the vector write of x - the complex multiply
+// in front - and the first DPP read; one s_nop 0 between the stages (each half then has two instructions between its write and its
+// next DPP read).
+template <int QA, int QB, bool NEG, int LEAD = 2>
+__device__ __forceinline__ void z3_stage2(f2& x, float ta, float tb) {
+    static_assert(QA >= 0 && QA < 3 && QB >= 0 && QB < 3 && QA != QB, "row qubits 0 .. 2 sit on lane bits 0, 1, 3");
+#define CPF_Z3_CTRL(Q) (Q == 0 ? "quad_perm:[1,0,3,2]" : (Q == 1 ? "quad_perm:[2,3,0,1]" : "row_ror:8"))
+#define CPF_Z3_ST2(CA, CB, SGN, LEADNOP)                                                                                       \
+    asm(LEADNOP "v_fmac_f32_dpp %0, %0, " SGN "%2 " CA " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                         \
+        "v_fmac_f32_dpp %1, %1, " SGN "%2 " CA " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                 \
+        "s_nop 0\n\tv_fmac_f32_dpp %0, %0, " SGN "%3 " CB " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                    \
+        "v_fmac_f32_dpp %1, %1, " SGN "%3 " CB " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x.x), "+v"(x.y) : "v"(ta), "v"(tb));
+#define CPF_Z3_ST2L(CA, CB, SGN) if constexpr (LEAD >= 2) { CPF_Z3_ST2(CA, CB, SGN, "s_nop 1\n\t") } else if constexpr (LEAD == 1) { CPF_Z3_ST2(CA, CB, SGN, "s_nop 0\n\t") } else { CPF_Z3_ST2(CA, CB, SGN, "") }
+#define CPF_Z3_ST2S(CA, CB) if constexpr (NEG) { CPF_Z3_ST2L(CA, CB, "-") } else { CPF_Z3_ST2L(CA, CB, "") }
+    if constexpr (QA == 0 && QB == 1) { CPF_Z3_ST2S("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]") }
+    else if constexpr (QA == 0 && QB == 2) { CPF_Z3_ST2S("quad_perm:[1,0,3,2]", "row_ror:8") }
+    else if constexpr (QA == 1 && QB == 0) { CPF_Z3_ST2S("quad_perm:[2,3,0,1]", "quad_perm:[1,0,3,2]") }
+    else if constexpr (QA == 1 && QB == 2) { CPF_Z3_ST2S("quad_perm:[2,3,0,1]", "row_ror:8") }
+    else if constexpr (QA == 2 && QB == 0) { CPF_Z3_ST2S("row_ror:8", "quad_perm:[1,0,3,2]") }
+    else { CPF_Z3_ST2S("row_ror:8", "quad_perm:[2,3,0,1]") }
+#undef CPF_Z3_ST2S
+#undef CPF_Z3_ST2L
+#undef CPF_Z3_ST2
+#undef CPF_Z3_CTRL
+}
+// Both stages of a block on the live matrix x (row qubits QA then QB; NEG: un-applied) AND four partner values of a STORED state o
+// that the products of this block (wave B) or of the next one (wave A) need: the moves read registers nobody is writing, so they
+// stand where the stages' wait states would be - no s_nop in the block.  The caller guarantees two wait states between the last
+// vector write of x and this statement's third instruction (the complex multiply in front and the two moves do).
+//   pre = (o.re at the partner on FA, o.re at the partner on FB), pim likewise for o.im
+#define CPF_Z3_C0 "quad_perm:[1,0,3,2]"
+#define CPF_Z3_C1 "quad_perm:[2,3,0,1]"
+#define CPF_Z3_C2 "row_ror:8"
+#define CPF_Z3_DPPT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define CPF_Z3_PAIRS6(M, ...)                                                                                               \
+    if constexpr (M##A == 0 && M##B == 1) { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C0, CPF_Z3_C1) }                                 \
+    else if constexpr (M##A == 0 && M##B == 2) { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C0, CPF_Z3_C2) }                            \
+    else if constexpr (M##A == 1 && M##B == 0) { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C1, CPF_Z3_C0) }                            \
+    else if constexpr (M##A == 1 && M##B == 2) { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C1, CPF_Z3_C2) }                            \
+    else if constexpr (M##A == 2 && M##B == 0) { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C2, CPF_Z3_C0) }                            \
+    else { CPF_Z3_BODY(__VA_ARGS__, CPF_Z3_C2, CPF_Z3_C1) }
+template <int QA, int QB, bool NEG, int FA, int FB>
+__device__ __forceinline__ void z3_stage2_fetch(f2& x, float ta, float tb, f2 o, f2& pre, f2& pim) {
+    static_assert(QA >= 0 && QA < 3 && QB >= 0 && QB < 3 && QA != QB && FA >= 0 && FA < 3 && FB >= 0 && FB < 3 && FA != FB, "row qubits 0 .. 2 sit on lane bits 0, 1, 3");
+#define CPF_Z3_BODY(SGN, CA, CB, GA, GB)                                                                                     \
+    asm("v_mov_b32_dpp %2, %6 " GA CPF_Z3_DPPT "v_mov_b32_dpp %4, %7 " GA CPF_Z3_DPPT                                        \
+        "v_fmac_f32_dpp %0, %0, " SGN "%8 " CA CPF_Z3_DPPT "v_fmac_f32_dpp %1, %1, " SGN "%8 " CA CPF_Z3_DPPT                \
+        "v_mov_b32_dpp %3, %6 " GB CPF_Z3_DPPT "v_mov_b32_dpp %5, %7 " GB CPF_Z3_DPPT                                        \
+        "v_fmac_f32_dpp %0, %0, " SGN "%9 " CB CPF_Z3_DPPT "v_fmac_f32_dpp %1, %1, " SGN "%9 " CB " row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+        : "+v"(x.x), "+v"(x.y), "=&v"(pre.x), "=&v"(pre.y), "=&v"(pim.x), "=&v"(pim.y) : "v"(o.x), "v"(o.y), "v"(ta), "v"(tb));
+#define CPF_Z3_STAGE_PAIRS(SGN)                                                                                              \
+    if constexpr (QA == 0 && QB == 1) { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C0, CPF_Z3_C1) }                                        \
+    else if constexpr (QA == 0 && QB == 2) { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C0, CPF_Z3_C2) }                                   \
+    else if constexpr (QA == 1 && QB == 0) { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C1, CPF_Z3_C0) }                                   \
+    else if constexpr (QA == 1 && QB == 2) { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C1, CPF_Z3_C2) }                                   \
+    else if constexpr (QA == 2 && QB == 0) { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C2, CPF_Z3_C0) }                                   \
+    else { CPF_Z3_PAIRS6(F, SGN, CPF_Z3_C2, CPF_Z3_C1) }
+    if constexpr (NEG) { CPF_Z3_STAGE_PAIRS("-") } else { CPF_Z3_STAGE_PAIRS("") }
+#undef CPF_Z3_STAGE_PAIRS
+#undef CPF_Z3_BODY
+}
+// the four partner values alone (a stored state: no wait states needed)
+template <int FA, int FB>
+__device__ __forceinline__ void z3_fetch(f2 o, f2& pre, f2& pim) {
+    static_assert(FA >= 0 && FA < 3 && FB >= 0 && FB < 3 && FA != FB, "row qubits 0 .. 2 sit on lane bits 0, 1, 3");
+#define CPF_Z3_BODY(GA, GB)                                                                                                  \
+    asm("v_mov_b32_dpp %0, %4 " GA CPF_Z3_DPPT "v_mov_b32_dpp %2, %5 " GA CPF_Z3_DPPT                                        \
+        "v_mov_b32_dpp %1, %4 " GB CPF_Z3_DPPT "v_mov_b32_dpp %3, %5 " GB " row_mask:0xf bank_mask:0xf bound_ctrl:1"         \
+        : "=&v"(pre.x), "=&v"(pre.y), "=&v"(pim.x), "=&v"(pim.y) : "v"(o.x), "v"(o.y));
+    if constexpr (FA == 0 && FB == 1) { CPF_Z3_BODY(CPF_Z3_C0, CPF_Z3_C1) }
+    else if constexpr (FA == 0 && FB == 2) { CPF_Z3_BODY(CPF_Z3_C0, CPF_Z3_C2) }
+    else if constexpr (FA == 1 && FB == 0) { CPF_Z3_BODY(CPF_Z3_C1, CPF_Z3_C0) }
+    else if constexpr (FA == 1 && FB == 2) { CPF_Z3_BODY(CPF_Z3_C1, CPF_Z3_C2) }
+    else if constexpr (FA == 2 && FB == 0) { CPF_Z3_BODY(CPF_Z3_C2, CPF_Z3_C0) }
+    else { CPF_Z3_BODY(CPF_Z3_C2, CPF_Z3_C1) }
+#undef CPF_Z3_BODY
+}
+// the three row-qubit partners of a value an asm statement has just written (two wait states in front)
+__device__ __forceinline__ void z3_partner3(f2 v, f2& p0, f2& p1, f2& p2) {
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %1, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %2, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %3, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %4, %6 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %5, %7 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(p0.x), "=&v"(p0.y), "=&v"(p1.x), "=&v"(p1.y), "=&v"(p2.x), "=&v"(p2.y) : "v"(v.x), "v"(v.y));
+}
+// The four products behind a block's Px / Py shares, halves of the live matrix v selected by op_sel (the compiler builds the
+// broadcast of v.y with a v_mov_b32 and then splits the register pair: two moves per block in round 5's listing):
+//   A (wave A: v = the cotangent w, partners of psi):  px =   v.x pim - v.y pre,  py = -(v.x pre + v.y pim)
+//   B (wave B: v = psi', partners of W):               px =   v.y pre - v.x pim,  py =   v.x pre + v.y pim
+template <bool WAVE_B>
+__device__ __forceinline__ void z3_products(f2 v, f2 pre, f2 pim, f2& px, f2& py) {
+    if constexpr (!WAVE_B)
+        asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %2, %4 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+            : "=&v"(px), "=&v"(py) : "v"(v), "v"(pre), "v"(pim));
+    else
+        asm("v_pk_mul_f32 %0, %2, %4 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %2, %4 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+            : "=&v"(px), "=&v"(py) : "v"(v), "v"(pre), "v"(pim));
+}
+// The penalty of one CP angle and its slope (penalty.py:44-71) as cpf_device.h penalty_lds evaluates them - the same piece, the same
+// two roundings - with the piece found without compares: the index is the number of break points below x, and a packed
+// (x - lo) * 2^40 clamped to [0, 1] is exactly 1 above a break point and 0 at or below it (x and the break points are float32
+// numbers of [0, 2 pi]: where they differ they differ by more than 2^-30; the product by a power of two is exact).  Four packed
+// FMAs and four adds where eight v_cmp / v_cndmask pairs each waited two states for their mask (round 5's listing: ~25 instructions).
+__device__ __forceinline__ float z3_penalty(const float* tab, int pen_kind, float ang, float& slope) {
+    if (pen_kind == 1) {                                      // penalty.py:74-76
+        slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
+        return fabsf(ang);
+    }
+    const float x = floor_mod_2pi(ang);
+    const float4 l0 = *reinterpret_cast<const float4*>(tab + PEN_LO);
+    const float4 l1 = *reinterpret_cast<const float4*>(tab + PEN_LO + 4);
+    constexpr float BIG = 1099511627776.f;                   // 2^40
+    const f2 xb = splat(x * BIG);
+    f2 c0, c1, c2, c3;
+    asm("v_pk_fma_f32 %0, %3, %4, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+        "v_pk_fma_f32 %1, %3, %5, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+        "v_pk_fma_f32 %2, %3, %6, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp"
+        : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(f2{BIG, BIG}), "v"(f2{l0.x, l0.y}), "v"(f2{l0.z, l0.w}), "v"(f2{l1.x, l1.y}), "v"(xb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c3) : "v"(f2{BIG, BIG}), "v"(f2{l1.z, l1.w}), "v"(xb));
+    const f2 cs01 = (c0 + c1) + (c2 + c3);
+    const int idx = (int)(cs01.x + cs01.y);
+    const float2 si = *reinterpret_cast<const float2*>(tab + PEN_SI + 2 * idx);
+    slope = si.x;
+    return __fadd_rn(__fmul_rn(si.x, x), si.y);
+}
 // the value held by the partner lane on row qubit Q (lane bits 0, 1, 3); every lane takes part
 template <int Q>
 __device__ __forceinline__ float z3_partner(float v) {
@@ -135,6 +281,16 @@ template <int Q>
 __device__ __forceinline__ int z3_partner(int v) {
     constexpr int CTRL = Q == 0 ? 0xB1 : (Q == 1 ? 0x4E : 0x128);
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// both halves of a complex value at the partner lane on row qubit Q, wait states included: for values an inline-asm statement has
+// just written (the compiler's hazard recogniser knows its own vector instructions only)
+template <int Q>
+__device__ __forceinline__ f2 z3_partner2(f2 v) {
+    f2 o;
+    if constexpr (Q == 0) asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(o.x), "=&v"(o.y) : "v"(v.x), "v"(v.y));
+    else if constexpr (Q == 1) asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(o.x), "=&v"(o.y) : "v"(v.x), "v"(v.y));
+    else asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(o.x), "=&v"(o.y) : "v"(v.x), "v"(v.y));
+    return o;
 }
 // value of lane ^ 1 (quad_perm [1,0,3,2]); every lane takes part
 __device__ __forceinline__ float z3_nb(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
@@ -160,29 +316,25 @@ __device__ __forceinline__ void z3_allsum(float& re, float& im, bool odd) {
     const z3_f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(odd ? i1 : r1, 1.0f, zero, 0, 0, 0);
     re = d2[0]; im = d2[1];
 #else
-    // cpf_device.h wave_sum2 with its two row_bcast stages as ONE v_add_f32_dpp each under a row mask (the compiler builds them from a
-    // zeroed register, a v_mov_b32_dpp and an add, with two wait states in front: 8 instructions more per call)
+    // Round 6: ONE v_permlane32_swap folds the wave's halves - lanes 0..31 then hold re(l) + re(l + 32), lanes 32..63 im(l - 32) +
+    // im(l) - so the four row stages and one row_bcast run on ONE register (5 DPP instructions instead of 12), and the totals are
+    // read from lanes 31 (re) and 63 (im).  tools/micro/issue_cost2.hip: 61 against 74 cycles per SIMD with two waves on it.
+    (void)odd;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(re), __float_as_uint(im), false, false);
+    float s = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     asm("s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
-        : "+v"(re), "+v"(im));
-    re = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(re), 63));
-    im = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(im), 63));
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+        : "+v"(s));
+    re = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 31));
+    im = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
 #endif
 }
 // three sums at once, stages interleaved (each fills the others' DPP wait states)
@@ -249,16 +401,15 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     const int64_t s_idx = (PAIRS == 1 || s_raw < a.nsamples) ? s_raw : (int64_t)a.nsamples - 1;
 
     // ---- sweep constants of this lane
-    bool lb[3]; float sg[3];
+    bool lb[3];
 #pragma unroll
-    for (int q = 0; q < 3; q++) { lb[q] = (lane >> L::row_lane_bit(q)) & 1; sg[q] = lb[q] ? 1.f : -1.f; }
+    for (int q = 0; q < 3; q++) lb[q] = (lane >> L::row_lane_bit(q)) & 1;
     const bool odd = lane & 1;
     const int col = L::col_index(lane, 0), row = L::row_index(lane, 0);
-    int kofs[LL]; f2 sgp[LL];                                // per layer position: the lane's table entry, (sg[up], sg[dn])
+    int kofs[LL];                                            // per layer position: the lane's table entry
     static_for([&](auto jj) __attribute__((always_inline)) {
         constexpr int J = decltype(jj)::value, UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
         kofs[J] = 4 * (2 * (lb[UP] ? 1 : 0) + (lb[DN] ? 1 : 0));
-        sgp[J] = f2{sg[UP], sg[DN]};
     }, typename make_iseq<LL>::type{});
     f2* sp = reinterpret_cast<f2*>(smem + Lds::STATES) + lane;             // sp[0]: wave A's state at the cut, sp[64]: wave B's
     float* part = smem + Lds::PART + lane;                                 // row r at part[ZYZ3_ROW r]
@@ -266,10 +417,22 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     penalty_table_init(smem, a, tid);
     if (tid == 0) *reinterpret_cast<float4*>(smem + Lds::REC1 + 8 * K) = make_float4(1.f, 0.f, 1.f, 0.f);
     if (tid < 3 * Lds::up4(K)) smem[Lds::PV + tid] = 0.f;
-    if (tid < 4) smem[Lds::MSF + tid] = 0.f;                 // [3]: the step counter wave A waits for - LDS keeps what the last workgroup left
+    if (tid < 8) smem[Lds::MSF + tid] = 0.f;                 // [3]: the step counter wave A waits for - LDS keeps what the last workgroup left
+    if (tid < 4) {
+        // gradient of the CP angle = k_t s11 + k_u pz_up + k_d pz_dn with (k_t, k_u, k_d) by where the entangler's phase sits in the held
+        // frame (ca, cb): cpf_zyz_math.h chain_cp's four branches, times -2 (round 5 compiled them into nested exec-mask regions)
+        const int ca = tid & 1, cb = tid >> 1;
+        *reinterpret_cast<float4*>(smem + Lds::CPT + 4 * tid) =
+            make_float4((ca == cb) ? -2.f : 2.f, cb ? 0.f : (ca ? 1.f : -1.f), ca ? 0.f : (cb ? 1.f : -1.f), 0.f);
+    }
 
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
-    auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Every barrier a wave passes is counted (one scalar add); the two waves compare their counts after the last step and poison the
+    // sample's results when they differ.  The step loops are only correct while the compiler keeps ONE barrier per phase and wave: a
+    // loop it split by lanes ran its s_barrier once per group of lanes and the two waves silently lost step (see "No branch on the
+    // lane ..." above) - with the count, every instance of every shape checks itself on every launch.
+    unsigned nbar = 0;
+    auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_add_u32 %0, %0, 1" : "+s"(nbar) :: "memory", "scc"); };
     // static structure: qubit of side w (block w >> 1, side w & 1)
     auto qubit_of = [&](int w) {
         int r = 0;
@@ -295,8 +458,16 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         if (sr < r_hi) {
             const int b = sr < 7 ? -1 : (sr - 7) / 5, j = sr < 7 ? sr : (sr - 7) % 5;
             const bool is_u = sr < 7 ? j == 6 : j == 4;
-            if (!is_u) k.d_tot = Lds::TOT + (b < 0 ? 3 * (j >> 1) + (j & 1) : Lds::row_blk(b) + 3 * (j >> 1) + (j & 1));
-            else {
+            if (!is_u) {
+                // a Px row is a plain sum over the lanes.  A Py row holds the UNSIGNED shares (round 6): its total carries the sign of
+                // the lane's bit of the row's qubit, which the eight parts give for nothing - Py = (bit clear) - (bit set), the
+                // z combination of that qubit - instead of one packed multiply per block in the sweeps
+                const int dst = Lds::TOT + (b < 0 ? 3 * (j >> 1) + (j & 1) : Lds::row_blk(b) + 3 * (j >> 1) + (j & 1));
+                if (j & 1) {
+                    const int q = b < 0 ? (j >> 1) : qubit_of(2 * b + (j >> 1));
+                    if (q == 0) k.dz0 = dst; else if (q == 1) k.dz1 = dst; else k.dz2 = dst;
+                } else k.d_tot = dst;
+            } else {
                 int dz[3] = {none, none, none};
                 if (b < 0) { dz[0] = Lds::TOT + 2; dz[1] = Lds::TOT + 5; dz[2] = Lds::TOT + 8; }
                 else { dz[qubit_of(2 * b)] = Lds::TOT + Lds::row_blk(b) + 2; dz[qubit_of(2 * b + 1)] = Lds::TOT + Lds::row_blk(b) + 5; }
@@ -339,7 +510,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
     float best = 0.f, first = 0.f;
     // HBM is touched at the two ends of the run only, and in whole rows: the pair's 128 threads read the sample's P initial angles
-    // contiguously into LDS (the rows of shares: free until the first gradient half) and copy them to both output slots; an owner lane
+    // contiguously into LDS (the rows of shares: free until the first gradient half) and copy them to output slot 0; an owner lane
     // takes its angles from there, and after the last step puts its best ones back for one contiguous store (instead of scattered
     // 4-byte accesses of the owner lanes; time-neutral, 4.37 / 4.33 ms).
     static_assert(Lds::SROWS * ZYZ3_ROW >= 9 + 7 * K, "the angles of a sample fit the scratch");
@@ -349,7 +520,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         for (int j = tid; j < P; j += 128) {
             const float v = a.init[s_idx * P + j];
             ang[j] = v;
-            if (live_pair) { a.out_params[(s_idx * 2) * P + j] = v; a.out_params[(s_idx * 2 + 1) * P + j] = v; }
+            if (live_pair) a.out_params[(s_idx * 2) * P + j] = v;          // slot 0: the initial angles; slot 1 is written once, after the last step
         }
         barrier();
     }
@@ -368,11 +539,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // Adam closes step `it - 1` (optax scale_by_adam, optimization.py:14-25: the same operations in the same order as the scalar form, per
     // half), then (cos, sin) of the half angles (slot 3: a CP angle, the full angle)
     // halfq: the lane owns slots 0 and 1 only (two lanes per item); sc01: what sin / cos take of slots 0, 1 (half angles; the full angle of a CP slot)
+    // The bias corrections come as RECIPROCALS from the host (round 6: two v_rcp_f32 fewer per wave and step) and one step ahead:
+    // the scalar load of step it + 1's pair is issued here, a whole step before its use (the knock-out of the load alone was 1 %).
+    f2 ibc_next = {1.f, 1.f};
+    { const float2 b0 = const_load_f2(a.ibias, 0); ibc_next = f2{b0.x, b0.y}; }
     auto adam_sincos = [&](int it, auto halfq, f2 sc01) __attribute__((always_inline)) {
         constexpr bool HALF = decltype(halfq)::value != 0;
         if (it > 0) {
-            const float2 bc = const_load_f2(a.bias, it - 1);
-            const f2 ibc = f2{__builtin_amdgcn_rcpf(bc.x), __builtin_amdgcn_rcpf(bc.y)};
+            const f2 ibc = ibc_next;
             const f2 m0 = pk_fma(splat(a.b1), mm01, splat(a.omb1) * g01);
             const f2 v0 = pk_fma(splat(a.b2), vv01, splat(a.omb2) * (g01 * g01));
             mm01 = m0; vv01 = v0;
@@ -390,6 +564,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 th23 = pk_fma(nlr23, u1, th23);
             }
         }
+        { const float2 bn = const_load_f2(a.ibias, it); ibc_next = f2{bn.x, bn.y}; }      // for step it + 1 (it <= T - 1: inside the table)
         f2 s01, c01;
         fast_sincos2(th01 * sc01, s01, c01);
         cs[0][0] = c01.x; cs[0][1] = s01.x; cs[1][0] = c01.y; cs[1][1] = s01.y;
@@ -401,8 +576,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
         }
     };
-    // loss and best-iterate tracking from T and the penalty values of the lane's sample (both waves: the same instructions on the same numbers)
-    // r x the sum of the K penalty values (both waves: the same additions in the same order)
+    // r x the sum of the K penalty values
     auto pen_reg = [&](const float4 (&pvq)[(K + 3) / 4]) __attribute__((always_inline)) {
         float pen_sum = 0.f;
         if (a.use_reg) {
@@ -412,26 +586,36 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         return a.use_reg ? a.r * pen_sum : 0.f;
     };
     // The best iterate's angles stay in registers (selects, no branch and no store inside the step) and are written once, by
-    // store_best, after the last step.
+    // put_best, after the last step.  ONE wave decides which iterate is the best so far - wave B, in its loss phase - and publishes
+    // the decision (Lds::MSF + 4); wave A follows it at the top of its next step, before Adam moves its angles (round 6: until then
+    // both waves formed the regularised loss and compared, and out_params[:, 1] was a consistent iterate only as long as the two
+    // copies of that arithmetic rounded alike).
     f2 bt01 = {0.f, 0.f}, bt23 = {0.f, 0.f};
     auto put_best = [&](float* ang) __attribute__((always_inline)) {          // the owner lane's best angles, back into the sample's row in LDS
         const float t0[4] = {bt01.x, bt01.y, bt23.x, bt23.y};
 #pragma unroll
         for (int k = 0; k < 4; k++) if (pj[k] >= 0) ang[pj[k]] = t0[k];
     };
-    auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss) __attribute__((always_inline)) {
+    auto hist_angles = [&](int it, int64_t sample, bool live) __attribute__((always_inline)) {      // keep_history: this step's angles of the lane's item
+#ifndef CPF_STAMPS
+        if (a.hist_params && live) {
+            const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.hist_params[(sample * a.T + it) * P + pj[k]] = t0[k];
+        }
+#endif
+    };
+    // wave B: loss, the decision, its own best angles
+    auto track = [&](int it, float tr, float ti, float reg, int64_t sample, bool live, bool writes_loss, float* take_dst) __attribute__((always_inline)) {
         const float loss = 1.f - fmaf(tr, tr, ti * ti) * a.inv_dim2;
         const float regloss = loss + reg;
         const bool take = it == 0 || regloss < best;         // strict: the first of equal losses stays (optimization.py:365-370 argmin)
         first = it == 0 ? regloss : first;
         best = take ? regloss : best;
         bt01 = take ? th01 : bt01; bt23 = take ? th23 : bt23;
-        const float t0[4] = {th01.x, th01.y, th23.x, th23.y};
+        if (writes_loss) *take_dst = take ? 1.f : 0.f;
+        hist_angles(it, sample, live);
 #ifndef CPF_STAMPS
-        if (a.hist_params && live) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (pj[k] >= 0) a.hist_params[(sample * a.T + it) * P + pj[k]] = t0[k];
-        }
         if (a.hist_loss && writes_loss && live) a.hist_loss[sample * a.T + it] = regloss;
 #endif
     };
@@ -473,6 +657,17 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         RowK rka[NRA];
 #pragma unroll
         for (int r = 0; r < NRA; r++) rka[r] = row_consts(0, SA, r);
+        // Where a block's five rows of shares start, per block, as LDS pointers kept in registers for the whole run (the empty asm
+        // makes them opaque): ds_write2_b32 reaches 1020 bytes from its base, so the compiler otherwise re-derives a base with a
+        // v_add_u32 in front of every second store of the gradient halves (round 5's listing: 35 of them per sample-step).
+        z3_lds_f* pb[M];
+        static_for([&](auto bb) __attribute__((always_inline)) {
+            constexpr int B = decltype(bb)::value;
+            pb[B] = (z3_lds_f*)(part + ZYZ3_ROW * Lds::srow_blk(B));
+            asm volatile("" : "+v"(pb[B]));
+        }, typename make_iseq<M>::type{});
+        z3_lds_f* pb_surf = (z3_lds_f*)part;
+        asm volatile("" : "+v"(pb_surf));
         barrier();                                           // constant records of the set-up
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -481,7 +676,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
                 const float* tot = smem + Lds::TOT + 3 * qa;
                 float gs[3] = {0.f, 0.f, 0.f};
-                if (it > 0) zyz::chain_surface(gs, tot[0], tot[1], tot[2], my_flip != 0.f ? 1 : 0, cs[1][0], cs[1][1], cs[2][0], cs[2][1]);
+                if (it > 0) {
+                    // wave B's verdict on the iterate of the step just closed (these are still its angles: Adam comes next)
+                    const float tk = smem[Lds::MSF + 4];
+                    zyz::chain_surface(gs, tot[0], tot[1], tot[2], my_flip != 0.f ? 1 : 0, cs[1][0], cs[1][1], cs[2][0], cs[2][1]);
+                    bt01 = tk != 0.f ? th01 : bt01;
+                }
                 const float g2 = z3_nb(gs[2]);              // the third angle's gradient, for the odd lane
                 g01 = (lane & 1) ? f2{g2, 0.f} : f2{gs[0], gs[1]};
                 adam_sincos(it, ic<1>{}, splat(0.5f));
@@ -497,7 +697,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                     } while (__builtin_amdgcn_readfirstlane(__float_as_int(seen)) != __float_as_int((float)(it + 1)));
                     const float th_cp = smem[Lds::PTH + (lane < K ? lane : K - 1)];
                     float sl;
-                    const float pv = penalty_lds(smem, a.pen_kind, th_cp, sl);
+                    const float pv = z3_penalty(smem, a.pen_kind, th_cp, sl);
                     pen_dst[0] = pv;                         // no branch on the lane here either (see publish_surface)
                     pen_dst[Lds::PSL - Lds::PV] = a.r * sl;
                 }
@@ -507,7 +707,6 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             CPF_STAMP(1)
             float4 ent[M];
             f2 own[M + 1];
-            float4 pvq[(K + 3) / 4];
             const float4 msf = *reinterpret_cast<const float4*>(smem + Lds::MSF);
             float2 fa[3], fb[3];
 #pragma unroll
@@ -525,17 +724,11 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = decltype(bb)::value, J = B % LL;
                 x = z3_cmul(f2{ent[B].x, ent[B].y}, x);
-                z3_stage<PL::v[2 * J]>(x, ent[B].z);
-                z3_stage<PL::v[2 * J + 1]>(x, ent[B].w);
+                z3_stage2<PL::v[2 * J], PL::v[2 * J + 1], false>(x, ent[B].z, ent[B].w);
                 own[B + 1] = x;
             }, typename make_iseq<M>::type{});
             sp[0] = x;                                       // psi(s_{M-1}): the only state the other wave reads
-            // This wave's forward and gradient halves are the shorter ones (wave B owns nothing but sweeps more blocks), its owner and
-            // loss phases the longer ones: the penalty sum (its values are this wave's own, from before the last barrier) is formed
-            // here and the best-iterate tracking waits until the gradient half is done - both in time the wave would spend waiting.
-#pragma unroll
-            for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(smem + Lds::PV)[k];
-            const float reg_a = pen_reg(pvq);
+            hist_angles(it, s_idx, live);                    // (keep_history only)
             CPF_STAMP(2)                                  // forward half
             barrier();
             CPF_STAMP(3)
@@ -544,42 +737,50 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             float tr = tt.x, ti = tt.y;
             z3_allsum(tr, ti, odd);
             f2 w = z3_cmul(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, w_c);       // the cotangent at the cut: f W, f = -T / N^2
-            if (a.T == 0 || it + 1 == iters) { track(it, tr, ti, reg_a, s_idx, live, false); break; }
+            if (a.T == 0 || it + 1 == iters) break;
             CPF_STAMP(4)                                  // loss
+            // A block of the gradient half: the partner lanes' psi(s_B) on the block's two qubits are at hand - fetched while the
+            // PREVIOUS block's stages ran, straight from the partner lanes' registers (the state is no longer a sweep's live value) -
+            // three complex products give the five shares, then the block is un-applied from the cotangent while the next block's
+            // partner values arrive.  19 instructions, no s_nop.
+            f2 pre, pim;                                     // (re up, re dn), (im up, im dn) of psi(s_B) at the partner lanes
+            z3_fetch<PL::v[2 * ((M - 1) % LL)], PL::v[2 * ((M - 1) % LL) + 1]>(own[M], pre, pim);
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = M - 1 - decltype(bb)::value, J = B % LL;
-                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::srow_blk(B);
+                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
                 const f2 o = own[B + 1];
-                // the partner lanes' psi(s_B) on the block's two qubits, straight from their registers (the state is no longer the
-                // sweep's live value, so the four moves wait for nothing and fill the sweep's dependency stalls): (re up, re dn), (im up, im dn)
-                const f2 pre = {z3_partner<UP>(o.x), z3_partner<DN>(o.x)}, pim = {z3_partner<UP>(o.y), z3_partner<DN>(o.y)};
-                // Im / Re of conj(w) psi[partner] for both qubits at once; Im(conj(w) psi) at the lane
-                const f2 PX = pk_fma(splat(w.x), pim, -(splat(w.y) * pre));
-                const f2 PY = pk_fma(splat(w.x), pre, splat(w.y) * pim) * sgp[J];
-                part[ZYZ3_ROW * (R0 + 0)] = PX.x;
-                part[ZYZ3_ROW * (R0 + 1)] = PY.x;
-                part[ZYZ3_ROW * (R0 + 2)] = PX.y;
-                part[ZYZ3_ROW * (R0 + 3)] = PY.y;
-                part[ZYZ3_ROW * (R0 + 4)] = fmaf(w.x, o.y, -w.y * o.x);
-                z3_stage<DN, true>(w, ent[B].w);
-                z3_stage<UP, true>(w, ent[B].z);
+                // Im of conj(w) psi[partner] and MINUS its real part for both qubits at once (the Py rows hold unsigned shares: the sign of
+                // the lane's bit is applied by the row sums, see row_consts); Im(conj(w) psi) at the lane
+                f2 PX, PY;
+                z3_products<false>(w, pre, pim, PX, PY);
+                pb[B][0] = PX.x;
+                pb[B][ZYZ3_ROW] = PY.x;
+                pb[B][2 * ZYZ3_ROW] = PX.y;
+                pb[B][3 * ZYZ3_ROW] = PY.y;
+                pb[B][4 * ZYZ3_ROW] = z3_cmul_conj(w, o).y;
+                if constexpr (B > 0) {
+                    constexpr int JN = (B - 1) % LL;
+                    z3_stage2_fetch<DN, UP, true, PL::v[2 * JN], PL::v[2 * JN + 1]>(w, ent[B].w, ent[B].z, own[B], pre, pim);
+                } else z3_stage2<DN, UP, true, 0>(w, ent[B].w, ent[B].z);
                 w = z3_cmul_conj(f2{ent[B].x, ent[B].y}, w);
             }, typename make_iseq<M>::type{});
-            {   // the surface slice s_-1: all three qubits, and the |11> sum of block 0
+            {   // the surface slice s_-1: all three qubits, and the |11> sum of block 0.  The partner is taken of the cotangent (the sums run
+                // over all lanes, so conj(w) psi[partner] and conj(w[partner]) psi add up to the same): ONE complex product per qubit
+                // gives the Py share (real part; its sign comes with the row sums) and the Px share (imaginary part)
                 const f2 o = own[0];
+                f2 wq[3];
+                z3_partner3(w, wq[0], wq[1], wq[2]);
                 static_for([&](auto qq) __attribute__((always_inline)) {
                     constexpr int Q = decltype(qq)::value;
-                    const f2 psq = {z3_partner<Q>(o.x), z3_partner<Q>(o.y)};
-                    const f2 zq = w * swp(psq), yq = w * psq;
-                    part[ZYZ3_ROW * (2 * Q + 0)] = zq.x - zq.y;
-                    part[ZYZ3_ROW * (2 * Q + 1)] = sg[Q] * (yq.x + yq.y);
+                    const f2 zq = z3_cmul_conj(wq[Q], o);
+                    pb_surf[ZYZ3_ROW * (2 * Q + 0)] = zq.y;
+                    pb_surf[ZYZ3_ROW * (2 * Q + 1)] = zq.x;
                 }, typename make_iseq<3>::type{});
-                part[ZYZ3_ROW * 6] = fmaf(w.x, o.y, -w.y * o.x);
+                pb_surf[ZYZ3_ROW * 6] = z3_cmul_conj(w, o).y;
             }
             lds_fence();
 #pragma unroll
             for (int r = 0; r < NRA; r++) row_sums(rka[r]);
-            track(it, tr, ti, reg_a, s_idx, live, false);
             CPF_STAMP(5)                                  // gradient half + row sums
             barrier();
             CPF_STAMP(6)
@@ -588,7 +789,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
 #endif
+        barrier();                                           // wave B's verdict on the last iterate is out
+        if (smem[Lds::MSF + 4] != 0.f) bt01 = th01;
         put_best(smem + Lds::PART);
+        if (lane == 0) smem[Lds::MSF + 5] = __uint_as_float(nbar + 1);      // this wave's barrier count (the one below included), for wave B to compare
         barrier();                                           // wave B of the pair stores the row
         return;
     }
@@ -670,6 +874,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     RowK rkb[NRB];
 #pragma unroll
     for (int r = 0; r < NRB; r++) rkb[r] = row_consts(SA, SROWS, r);
+    z3_lds_f* pb[K - M];                                     // where each block's rows of shares start (see wave A)
+    static_for([&](auto bb) __attribute__((always_inline)) {
+        constexpr int B = M + decltype(bb)::value;
+        pb[B - M] = (z3_lds_f*)(part + ZYZ3_ROW * Lds::srow_blk(B));
+        asm volatile("" : "+v"(pb[B - M]));
+    }, typename make_iseq<K - M>::type{});
+    const float th_cp0 = cp_angle();                         // the initial CP angle of a has_cp lane, for the epilogue's reg recompute
+    float* const take_dst = osmem + Lds::MSF + 4;
     barrier();                                               // penalty table, constant records: written by wave A's lanes
 #ifdef CPF_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -740,13 +952,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             constexpr int B = M + decltype(bb)::value;
             ent[B - M] = *reinterpret_cast<const float4*>(tab + 16 * B + kofs[B % LL]);
         }, typename make_iseq<K - M>::type{});
-        f2 x = z3_cmul_conj(z3_cmul(f2{lf[2].x, lf[2].y}, z3_cmul(f2{lf[1].x, lf[1].y}, f2{lf[0].x, lf[0].y})), vt);
+        f2 x, xs;                                            // W(s_b) as the gradient half will read it, and the copy the next block's stages overwrite
+        z3_cmul_conj2(z3_cmul(f2{lf[2].x, lf[2].y}, z3_cmul(f2{lf[1].x, lf[1].y}, f2{lf[0].x, lf[0].y})), vt, x, xs);
         own[K - M] = x;
         static_for([&](auto bb) __attribute__((always_inline)) {
             constexpr int B = K - 1 - decltype(bb)::value, J = B % LL;
-            z3_stage<PL::v[2 * J + 1], true>(x, ent[B - M].w);
-            z3_stage<PL::v[2 * J], true>(x, ent[B - M].z);
-            x = z3_cmul_conj(f2{ent[B - M].x, ent[B - M].y}, x);
+            z3_stage2<PL::v[2 * J + 1], PL::v[2 * J], true>(xs, ent[B - M].w, ent[B - M].z);
+            if constexpr (B > M) z3_cmul_conj2(f2{ent[B - M].x, ent[B - M].y}, xs, x, xs);
+            else x = z3_cmul_conj(f2{ent[B - M].x, ent[B - M].y}, xs);
             own[B - M] = x;                                                  // W(s_{B-1})
         }, typename make_iseq<K - M>::type{});
         sp[64] = x;                                   // W(s_{M-1}): the only state the other wave reads
@@ -771,7 +984,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 z3_allsum(tr1, ti1, odd);
                 otr = upper ? tr1 : tr; oti = upper ? ti1 : ti;
             }
-            track(it, otr, oti, pen_reg(pvq), os_idx, ovs, il == 0);
+            track(it, otr, oti, pen_reg(pvq), os_idx, ovs, il == 0, take_dst);
         }
         if (a.T == 0) break;
         if (it + 1 == iters) break;                   // the last step's gradient would move the angles past the last evaluated iterate
@@ -781,21 +994,19 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         {
             f2 pp = z3_cmul_conj(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, psi_c);
             static_for([&](auto bb) __attribute__((always_inline)) {
-                    constexpr int B = M + decltype(bb)::value, J = B % LL;
-                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1], R0 = Lds::srow_blk(B);
+                constexpr int B = M + decltype(bb)::value, J = B % LL;
+                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
                 pp = z3_cmul(f2{ent[B - M].x, ent[B - M].y}, pp);
-                z3_stage<UP>(pp, ent[B - M].z);
-                z3_stage<DN>(pp, ent[B - M].w);
                 const f2 o = own[B - M + 1];                                      // W(s_B)
-                const f2 pre = {z3_partner<UP>(o.x), z3_partner<DN>(o.x)}, pim = {z3_partner<UP>(o.y), z3_partner<DN>(o.y)};      // W(s_B) at the partner lanes
-                // the roles swapped: Im / Re of conj(W[partner]) psi' (the sign of the y sums changes), Im(conj(W) psi') at the lane
-                const f2 PX = pk_fma(splat(pp.y), pre, -(splat(pp.x) * pim));
-                const f2 PY = pk_fma(splat(pp.x), pre, splat(pp.y) * pim) * -sgp[J];
-                part[ZYZ3_ROW * (R0 + 0)] = PX.x;
-                part[ZYZ3_ROW * (R0 + 1)] = PY.x;
-                part[ZYZ3_ROW * (R0 + 2)] = PX.y;
-                part[ZYZ3_ROW * (R0 + 3)] = PY.y;
-                part[ZYZ3_ROW * (R0 + 4)] = fmaf(o.x, pp.y, -o.y * pp.x);
+                f2 pre, pim, PX, PY;                                              // W(s_B) at the partner lanes: (re up, re dn), (im up, im dn)
+                z3_stage2_fetch<UP, DN, false, UP, DN>(pp, ent[B - M].z, ent[B - M].w, o, pre, pim);
+                // the roles swapped: Im / Re of conj(W[partner]) psi' (unsigned: the row sums sign the Py rows), Im(conj(W) psi') at the lane
+                z3_products<true>(pp, pre, pim, PX, PY);
+                pb[B - M][0] = PX.x;
+                pb[B - M][ZYZ3_ROW] = PY.x;
+                pb[B - M][2 * ZYZ3_ROW] = PX.y;
+                pb[B - M][3 * ZYZ3_ROW] = PY.y;
+                pb[B - M][4 * ZYZ3_ROW] = z3_cmul_conj(o, pp).y;
             }, typename make_iseq<K - M>::type{});
         }
         lds_fence();
@@ -810,13 +1021,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             const float* tot = osmem + Lds::TOT;
             const float px = tot[rowP], py = tot[rowP + 1], pz = tot[rowP + 2];
             const float s11 = tot[row_s11], pzu = tot[row_pzu], pzd = tot[row_pzd];
+            const float4 kcp = *reinterpret_cast<const float4*>(osmem + Lds::CPT + 4 * cacb);
             auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
                 const int k = (idx - 1) >> 1;
                 c = cs[k][0]; sn = cs[k][1]; kind = 0;
             };
             float gp[4] = {0.f, 0.f, 0.f, 0.f};
             zyz::chain_side<ROT & 0xFFFF>(gp, px, py, pz, sd, rrec, NR, iside);
-            if (ENT == 0) gp[3] = zyz::chain_cp(s11, pzu, pzd, cacb, 1.f);
+            if (ENT == 0) gp[3] = fmaf(kcp.x, s11, fmaf(kcp.y, pzu, kcp.z * pzd));
             if constexpr (S2) {                           // slots 2, 3 go to the odd lane beside the main lane
                 const float n2 = z3_nb(gp[2]), n3 = z3_nb(gp[3]);
                 g01 = odd2 ? f2{n2, n3} : f2{gp[0], gp[1]};
@@ -829,18 +1041,23 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #endif
 
     // ---- epilogue (optimization.py:365-370, cp_utils.py:144-164): reg recompute, loss = regloss - reg, argmin, CZ count, entry-loss flag
+    barrier();                                               // wave A takes the verdict on the last iterate
     if (owner_wave) put_best(osmem + Lds::PART);
+    if (lane == 0) smem[Lds::MSF + 6] = __uint_as_float(nbar + 1);          // this wave's barrier count, the one below included
     barrier();
     if (PAIRS == 1 || s_raw < a.nsamples) {
         const float* ang = smem + Lds::PART;
         for (int j = lane; j < P; j += 64) a.out_params[(s_idx * 2 + 1) * P + j] = ang[j];
     }
     if (owner_wave) {
+        // every wave of the workgroup passed the same barriers or the run is void: a step loop the compiler split by lanes lets a wave
+        // pass one more than once per phase (see the head of this file); the results are poisoned rather than silently wrong
+        const bool in_step = __float_as_uint(osmem[Lds::MSF + 5]) == nbar && __float_as_uint(osmem[Lds::MSF + 6]) == nbar;
+        if (!in_step) { first = __builtin_nanf(""); best = first; }
         const int bi = (best < first) ? 1 : 0;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (has_cp) {
-            const int j = S2 ? pj[1] : pj[3];
-            const float t0 = a.out_params[(os_idx * 2) * P + j], t1 = S2 ? bt01.y : bt23.y;      // the initial CP angle (stored by the set-up), the best one
+            const float t0 = th_cp0, t1 = S2 ? bt01.y : bt23.y;      // the initial CP angle, the best one
             float sl;
             if (a.use_reg) { acc0 = penalty_lds(osmem, a.pen_kind, t0, sl); acc1 = penalty_lds(osmem, a.pen_kind, t1, sl); }
             acc2 = cz_value(bi ? t1 : t0, a.thr_cp);
@@ -853,7 +1070,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             a.out_regloss[os_idx * 2 + 0] = first; a.out_regloss[os_idx * 2 + 1] = best;
             a.out_reg[os_idx * 2 + 0] = reg0;      a.out_reg[os_idx * 2 + 1] = reg1;
             a.out_loss[os_idx * 2 + 0] = l0;       a.out_loss[os_idx * 2 + 1] = l1;
-            a.out_cz[os_idx] = (int32_t)acc2;
+            a.out_cz[os_idx] = in_step ? (int32_t)acc2 : -1;
             a.out_pass[os_idx] = ((bi ? l1 : l0) <= a.entry_loss) ? 1 : 0;
         }
     }

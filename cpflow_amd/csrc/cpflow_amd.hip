@@ -113,7 +113,7 @@ struct cpf_plan {
     bool force_generic = false;      // CPF_FORCE_GENERIC=1: always use the generic per-gate kernel (A/B testing)
     std::vector<uint8_t> h_pkind;
     std::vector<int4> h_prog;
-    DevBuf d_pkind, d_bias;
+    DevBuf d_pkind, d_bias, d_ibias;
     cpf::KArgs base{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -1122,6 +1122,10 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     const float b1f = (float)pb->b1, b2f = (float)pb->b2;
     for (int t = 1; t <= pl->T; t++)
         bias[t - 1] = make_float2(1.0f - powf(b1f, (float)t), 1.0f - powf(b2f, (float)t));
+    // ... and their float32 reciprocals (the two-ended 3-qubit kernel multiplies: m / (1 - b1^t) as m * (1 / (1 - b1^t)), the
+    // reciprocal correctly rounded here instead of v_rcp_f32's 1 ulp on the device)
+    std::vector<float2> ibias(bias.size(), make_float2(1.0f, 1.0f));
+    for (int t = 1; t <= pl->T; t++) ibias[t - 1] = make_float2(1.0f / bias[t - 1].x, 1.0f / bias[t - 1].y);
 
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) {
@@ -1136,6 +1140,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     }
     up(pl->d_pkind, pl->h_pkind.data(), (size_t)P);
     up(pl->d_bias, bias.data(), bias.size() * sizeof(float2));
+    up(pl->d_ibias, ibias.data(), ibias.size() * sizeof(float2));
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     hipDeviceProp_t prop;
@@ -1153,6 +1158,7 @@ int32_t cpf_plan_create(const cpf_problem* pb, int32_t device, cpf_plan** out_pl
     a.n_actual = n;
     a.pkind = pl->d_pkind.as<uint8_t>();
     a.bias = pl->d_bias.as<float2>();
+    a.ibias = pl->d_ibias.as<float2>();
     build_pieces(pb->penalty, a.pc);
     a.pen_kind = pb->penalty.kind;
     a.prio = 0;
