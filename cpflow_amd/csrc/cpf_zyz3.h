@@ -87,7 +87,7 @@ struct Zyz3Lds {                                  // float offsets, per sample; 
     static constexpr int TAB = PSL + up4(K);      // K x 4 entries x {d.re, d.im, t_up signed, t_dn signed}
     static constexpr int SURFM = TAB + 16 * K;    // 3 x {S, F S} x 2x2 complex: both variants of each surface matrix
     static constexpr int MSF = SURFM + 48;        // the three flip parities (floats 0 / 1); [3] the step counter wave A waits for;
-                                                  // [4] "this step's iterate is the best so far" (wave B decides, wave A follows); 3 spare
+                                                  // [4] "this step's iterate is the best so far" (wave B decides, wave A follows); [7] scratch
                                                   // [5], [6] the barrier counts of the sample's waves A and B (compared after the last step)
     static constexpr int CPT = MSF + 8;           // 4 x {k_t, k_u, k_d, -}: the CP angle's chain rule by (ca | cb << 1) (zyz::chain_cp as a table)
     static constexpr int TOT = CPT + 16;          // the ROWS sums, one spare slot behind them for stores that mean nothing
@@ -363,6 +363,23 @@ __device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upp
     x = upper ? x1 : x0; y = upper ? y1 : y0; z = upper ? z1 : z0;
 }
 
+#ifndef CPF_Z3_HWSINCOS
+#define CPF_Z3_HWSINCOS 1        // A/B: 1 = (cos, sin) on v_sin_f32 / v_cos_f32 behind a two-constant reduction to [-pi, pi] (max error 3.7e-7
+                                 // against fast_sincos2's 6e-8, profiles/r05_hw_sincos_accuracy.txt), 0 = the polynomials of cpf_device.h
+#endif
+__device__ __forceinline__ void z3_sincos2(f2 x, f2& sn, f2& cn) {
+#if CPF_Z3_HWSINCOS
+    const f2 t = x * splat(0.15915494309189535f);
+    const f2 k = f2{rintf(t.x), rintf(t.y)};
+    f2 r = pk_fma(-k, splat(6.28318548202514648f), x);
+    r = pk_fma(-k, splat(-1.74845553146951715e-7f), r);
+    const f2 rev = r * splat(0.15915494309189535f);
+    sn = f2{__builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y)};
+    cn = f2{__builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y)};
+#else
+    fast_sincos2(x, sn, cn);
+#endif
+}
 // ROT: rotation string and entangler (cpf_blocks.h rot_pack / rot_with_ent); KC: blocks; MC: blocks of wave A (1 .. KC-1);
 // PAIRS: samples per workgroup (1 or 2); UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20).
 // PAIRS = 2 (2 K <= 32 sides; a switch, no launch takes it by default): four waves, two samples, each with its own copy of the LDS
@@ -566,13 +583,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }
         { const float2 bn = const_load_f2(a.ibias, it); ibc_next = f2{bn.x, bn.y}; }      // for step it + 1 (it <= T - 1: inside the table)
         f2 s01, c01;
-        fast_sincos2(th01 * sc01, s01, c01);
+        z3_sincos2(th01 * sc01, s01, c01);
         cs[0][0] = c01.x; cs[0][1] = s01.x; cs[1][0] = c01.y; cs[1][1] = s01.y;
         if constexpr (HALF) {                               // slots 2, 3: the neighbouring (odd) lane's pair
             cs[2][0] = z3_nb(c01.x); cs[2][1] = z3_nb(s01.x); cs[3][0] = z3_nb(c01.y); cs[3][1] = z3_nb(s01.y);
         } else {
             f2 s23, c23;
-            fast_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);
+            z3_sincos2(th23 * f2{0.5f, 1.f}, s23, c23);
             cs[2][0] = c23.x; cs[2][1] = s23.x; cs[3][0] = c23.y; cs[3][1] = s23.y;
         }
     };
@@ -613,7 +630,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         first = it == 0 ? regloss : first;
         best = take ? regloss : best;
         bt01 = take ? th01 : bt01; bt23 = take ? th23 : bt23;
-        if (writes_loss) *take_dst = take ? 1.f : 0.f;
+        *take_dst = take ? 1.f : 0.f;                        // (the lanes that do not speak for a sample store into scratch)
         hist_angles(it, sample, live);
 #ifndef CPF_STAMPS
         if (a.hist_loss && writes_loss && live) a.hist_loss[sample * a.T + it] = regloss;
@@ -642,7 +659,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         // edge made the compiler split the loop by lanes - the barrier at its top then ran once per group of lanes.
         float* const pub = smem + (is_qubit ? Lds::SURFM + 16 * qa : Lds::PART + 16 * lane);
         static_assert(Lds::SROWS * ZYZ3_ROW >= 64 * 16, "scratch for the lanes without a qubit");
-        const unsigned flag_addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)(smem + Lds::MSF + 3);      // LDS byte address
+        unsigned flag_addr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float*)(smem + Lds::MSF + 3);      // LDS byte address
+        asm volatile("" : "+v"(flag_addr));                  // (opaque: the compiler otherwise re-derives it, null check of the cast included, in every poll)
         float* const pen_dst = smem + (lane < K ? Lds::PV + lane : Lds::PART + 2 * lane);      // (the scratch of the matrices again: stored later, read never)
         static_assert(Lds::SROWS * ZYZ3_ROW >= 128 + (Lds::PSL - Lds::PV), "scratch for the lanes without a CP angle");
         auto publish_surface = [&]() __attribute__((always_inline)) {
@@ -881,7 +899,18 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         asm volatile("" : "+v"(pb[B - M]));
     }, typename make_iseq<K - M>::type{});
     const float th_cp0 = cp_angle();                         // the initial CP angle of a has_cp lane, for the epilogue's reg recompute
-    float* const take_dst = osmem + Lds::MSF + 4;
+    // Where this lane's owner-phase stores go: the real slot where the lane owns one, its own 16 bytes of the rows of shares (dead
+    // between the row sums and the next gradient half) where it does not - so that the owner and loss phases store without a branch on
+    // the lane (round 5's listing: an s_and_saveexec / s_or pair around each of seven stores per step)
+    float* const dummy = osmem + Lds::PART + 4 * il + (upper ? 128 : 0);
+    float* const take_dst = osmem + Lds::MSF + (il == 0 ? 4 : 7);      // (stored in the LOSS phase, while wave A fills the rows of shares: a spare slot, not `dummy`)
+    float* const pth_dst = has_cp ? osmem + Lds::PTH + ib : dummy;
+    float* const flag_dst = il == 0 ? osmem + Lds::MSF + 3 : dummy;
+    float* const rec_dst = is_side ? osmem + Lds::REC1 + 4 * iw : dummy;
+    float* const msf_dst = first_q >= 0 ? osmem + Lds::MSF + first_q : dummy;
+    float* const tab_dst = is_side ? osmem + Lds::TAB + 16 * ib + 8 * iside : osmem + Lds::PART + 256 + 8 * lane;
+    const float* const psl_src = osmem + Lds::PSL + (has_cp ? ib : 0);
+    static_assert(Lds::SROWS * ZYZ3_ROW >= 256 + 8 * 64, "scratch for the lanes without a table entry");
     barrier();                                               // penalty table, constant records: written by wave A's lanes
 #ifdef CPF_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -892,9 +921,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         if (it > 0 && has_cp && a.use_reg) { if constexpr (S2) g01.y += psl; else g23.y += psl; }
         adam_sincos(it, ic<S2 ? 1 : 0>{}, sc01);
         if (ENT == 0 && a.use_reg) {                          // wave A evaluates the penalty of the CP angles: the angles, then the step counter it waits for
-            if (has_cp) osmem[Lds::PTH + ib] = cp_angle();
+            *pth_dst = cp_angle();
             lds_fence();
-            if (il == 0) osmem[Lds::MSF + 3] = (float)(it + 1);
+            *flag_dst = (float)(it + 1);
         }
         {
             auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
@@ -902,10 +931,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 c = cs[k][0]; sn = cs[k][1]; kind = 0;
             };
             sd = zyz::side_build<ROT & 0xFFFF>(rrec, NR, iside);
-            if (is_side) *reinterpret_cast<float4*>(osmem + Lds::REC1 + 4 * iw) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
+            *reinterpret_cast<float4*>(rec_dst) = make_float4(sd.l0.re, sd.l0.im, sd.l1.re, sd.l1.im);
             const unsigned long long fbits = __builtin_amdgcn_ballot_w64(is_side && sd.f != 0);
             sd.m = __popcll(fbits & later) & 1;
-            if (first_q >= 0) osmem[Lds::MSF + first_q] = (float)(sd.m ^ sd.f);      // every flip on the qubit: those later than its first side, and that side's own
+            *msf_dst = (float)(sd.m ^ sd.f);      // every flip on the qubit: those later than its first side, and that side's own
             lds_fence();
             const float4 pl = *reinterpret_cast<const float4*>(osmem + prev_off);
             const zyz::EPair e = zyz::side_epair(sd, true, zyz::c2(pl.x, pl.y), zyz::c2(pl.z, pl.w));      // "no previous side" reads the identity record
@@ -929,8 +958,8 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             const float tu = iside ? pt : sd.t, td = iside ? sd.t : pt;
             const float tus = iside ? tu : -tu;
             cacb = e.c | (pc << 1);
-            if (is_side) {
-                float4* dst = reinterpret_cast<float4*>(osmem + Lds::TAB + 16 * ib + 8 * iside);
+            {
+                float4* dst = reinterpret_cast<float4*>(tab_dst);
                 dst[0] = make_float4(d0.x, d0.y, tus, -td);
                 dst[1] = make_float4(d1.x, d1.y, tus, td);
             }
@@ -971,7 +1000,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         const f2 psi_c = sp[0];
 #pragma unroll
         for (int k = 0; k < (K + 3) / 4; k++) pvq[k] = reinterpret_cast<const float4*>(osmem + Lds::PV)[k];
-        if (has_cp) psl = osmem[Lds::PSL + ib];
+        psl = *psl_src;
         const f2 tt = z3_cmul_conj(x, psi_c);
         float tr = tt.x, ti = tt.y;
         z3_allsum(tr, ti, odd);

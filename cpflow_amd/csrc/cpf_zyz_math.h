@@ -85,21 +85,21 @@ CPF_ZHD Side side_build(const Rec& rec, int n_rot, int side) {
         }
         p = pn; q = qn;
     }
-    float n2 = p.re * p.re + p.im * p.im, m2 = q.re * q.re + q.im * q.im;
+    const float n2 = p.re * p.re + p.im * p.im, m2 = q.re * q.re + q.im * q.im;
     Side sd;
-    sd.f = m2 > n2 ? 1 : 0;
+    // Selects, not branches (the owner phase of the two-ended 3-qubit kernel is on every step's critical path, and the compiler turned
+    // the two `if` blocks this used to be into exec-mask regions of moves): the same operations on the same numbers.
+    const bool fl = m2 > n2;                 // A F^-1 = [[conj q, p], [-conj p, q]]
+    sd.f = fl ? 1 : 0;
     sd.m = 0;
-    if (sd.f) {                              // A F^-1 = [[conj q, p], [-conj p, q]]
-        const C2 pp = cconj(q), qq = c2(-p.re, p.im);
-        p = pp; q = qq;
-        const float tmp = n2; n2 = m2; m2 = tmp;
-    }
-    const float ip = zrsqrt(n2);
-    sd.l0 = cscale(p, ip);
-    const bool ok = m2 > 1e-30f;
-    const float iq = ok ? zrsqrt(m2) : 0.f;
-    sd.l1 = ok ? cscale(q, iq) : c2(1.f, 0.f);
-    sd.t = ok ? (m2 * iq) * ip : 0.f;
+    const C2 pp = c2(fl ? q.re : p.re, fl ? -q.im : p.im), qq = c2(fl ? -p.re : q.re, fl ? p.im : q.im);
+    const float nn = fl ? m2 : n2, mm = fl ? n2 : m2;
+    const float ip = zrsqrt(nn);
+    sd.l0 = cscale(pp, ip);
+    const bool ok = mm > 1e-30f;
+    const float iq = zrsqrt(ok ? mm : 1.f);
+    sd.l1 = c2(ok ? qq.re * iq : 1.f, ok ? qq.im * iq : 0.f);
+    sd.t = ok ? (mm * iq) * ip : 0.f;
     // the scale from the tangent that is actually applied: sc [[1, -t], [t, 1]] is then unitary to rounding whatever the
     // roundings of (p, q) were (sc = |p| would inherit their |p|^2 + |q|^2 - 1)
     sd.sc = zrsqrt(1.f + sd.t * sd.t);
