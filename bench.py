@@ -83,35 +83,100 @@ def launch_ranks(n):
     return 1 if failed else 0
 
 
-def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=12.0):
-    """Time the CPU restatement (oracle/, a C port of the JAX path, OpenMP over samples) on the
-    host cores, on a bounded sample of the same workload.  Reported, never shipped."""
+def usable_cores():
+    """The cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a job a share of
+    its host: 128 hardware threads visible, a fraction of them usable - running one OpenMP thread per VISIBLE core on such a box
+    oversubscribes the share several times over and was what round 5's `cores: 128` line did)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                quota, period = (None if parts[0] == 'max' else float(parts[0])), float(parts[1])
+            else:
+                quota = float(parts[0])
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f2:
+                    period = float(f2.read())
+                quota = None if quota <= 0 else quota
+            if quota:
+                n = max(1, min(n, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(wl, layer, K, target, rot, T, r, budget_s=10.0):
+    """Time the CPU restatement (oracle/, a C port of the JAX path, OpenMP over samples) on the host cores, on a bounded sample of
+    the same workload: the scalar float32 build (`kind: "port"`, the line's `cpu_baseline`), the same run vectorised over 16
+    samples at a time (`simd`: kind "port-simd", oracle/cpf_oracle_simd.h), and BASELINE config 1 - the reference's own
+    CPU-runnable case (README.md:35: "from one to five minutes" for its static() call) - as wall seconds of its raw stage
+    (`config1`).  Reported, never shipped, never the target."""
     import oracle
+    from cpflow_amd import workloads
     lib_path = None
     try:
         oracle.build(native=True)
         lib_path = os.path.join(ROOT, 'oracle', '_build', 'libcpf_oracle_native.so')
     except Exception:
         pass
-    cal = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=min(T, 20), lib_path=lib_path)
-    cores = int(cal.lib.cpfo_max_threads())
-    init = cal.initial_angles(0, cores)
-    t0 = time.time()
-    cal.run(init, np.float32, nthreads=cores)          # calibration: one sample per core, 20 iterations
-    per_step = max(time.time() - t0, 1e-4) / min(T, 20)
-    # ~budget_s seconds of work: all T iterations on whole multiples of the core count when one batch of `cores` samples
-    # fits the budget, otherwise `cores` samples over as many iterations as fit (rows of the same seed-0 angle matrix)
-    reps = int(budget_s / (per_step * T))
-    S, T_run = (int(min(cores * reps, 65536)), T) if reps >= 1 else (cores, max(20, int(budget_s / per_step)))
-    orc = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=T_run, lib_path=lib_path)
-    init = orc.initial_angles(0, S)
-    t0 = time.time()
-    orc.run(init, np.float32, nthreads=cores)
-    dt = time.time() - t0
-    return {'value': S * T_run / dt, 'unit': 'sample-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{S} samples (seed-0 initial angles) x {T_run} iterations of the same workload ({wl.name}: {wl.title}), '
-                      f'float32 C restatement of the JAX path (oracle/cpf_oracle.c, OpenMP, '
-                      f'{"-march=native" if lib_path else "portable -O3"}), {dt:.1f} s'}
+    flags = '-march=native' if lib_path else 'portable -O3'
+    cores = usable_cores()
+
+    def timed(run, budget):
+        """~budget seconds of work: all T iterations on whole multiples of the core count (x 16 lanes for the SIMD build) when such a
+        batch fits the budget, otherwise one batch over as many iterations as fit (rows of the same seed-0 angle matrix)."""
+        simd = run == 'run_simd'
+        batch = cores * (16 if simd else 1)
+        cal = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=min(T, 20), lib_path=lib_path)
+        init = cal.initial_angles(0, batch)
+        for _ in range(2):              # the first call pays for the thread pool and the page faults
+            t0 = time.time()
+            getattr(cal, run)(init, nthreads=cores) if simd else cal.run(init, np.float32, nthreads=cores)
+            per_step = max(time.time() - t0, 1e-5) / (min(T, 20) + 1)
+        reps = int(budget / (per_step * T))
+        S, T_run = (int(min(batch * reps, 1 << 20)), T) if reps >= 1 else (batch, max(20, int(budget / per_step)))
+        orc = oracle.Oracle(layer, K, target, rot, r=r, num_gd_iterations=T_run, lib_path=lib_path)
+        init = orc.initial_angles(0, S)
+        t0 = time.time()
+        getattr(orc, run)(init, nthreads=cores) if simd else orc.run(init, np.float32, nthreads=cores)
+        dt = time.time() - t0
+        return S, T_run, dt
+
+    S, T_run, dt = timed('run', budget_s)
+    out = {'value': S * T_run / dt, 'unit': 'sample-steps/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{S} samples (seed-0 initial angles) x {T_run} iterations of the same workload ({wl.name}: {wl.title}), float32 C '
+                     f'restatement of the JAX path (oracle/cpf_oracle.c, scalar, OpenMP over samples on the {cores} cores this job may '
+                     f'use of {os.cpu_count()} visible, {flags}), {dt:.1f} s'}
+    try:
+        S2, T2, dt2 = timed('run_simd', budget_s)
+        out['simd'] = {'value': S2 * T2 / dt2, 'unit': 'sample-steps/s', 'cores': cores, 'kind': 'port-simd',
+                       'sample': f'{S2} samples x {T2} iterations, the same restatement over 16 samples at a time (oracle/cpf_oracle_simd.h: '
+                                 f'structure of arrays, the scalar build\'s operations in its order, libmvec sinf / cosf; {flags}), {dt2:.1f} s'}
+    except NotImplementedError as e:
+        out['simd'] = {'value': None, 'kind': 'port-simd', 'sample': f'not covered: {e}'}
+    except Exception as e:
+        out['simd'] = {'value': None, 'kind': 'port-simd', 'sample': f'failed: {e}'}
+    try:
+        w1 = workloads.CONFIGS['cfg1']
+        o1 = oracle.Oracle(w1.layer, w1.num_cp_gates, w1.target, w1.rotation_gates, r=w1.r, num_gd_iterations=w1.num_gd_iterations, lib_path=lib_path)
+        init = o1.initial_angles(w1.seed, w1.samples_per_gpu)
+        t0 = time.time()
+        o1.run(init, np.float32, nthreads=min(cores, w1.samples_per_gpu))
+        d1 = time.time() - t0
+        t0 = time.time()
+        o1.run_simd(init, nthreads=1)
+        d1s = time.time() - t0
+        out['config1'] = {'workload': f'cfg1: {w1.title}, num_cp_gates={w1.num_cp_gates}, num_samples={w1.samples_per_gpu}, '
+                                      f'num_gd_iterations={w1.num_gd_iterations} (BASELINE configs[0], the README run; raw stage only)',
+                          'wall_s': d1, 'cores': min(cores, w1.samples_per_gpu), 'kind': 'port',
+                          'wall_s_simd': d1s, 'cores_simd': 1, 'sample_steps_per_s': w1.samples_per_gpu * w1.num_gd_iterations / d1,
+                          'reference_says': 'README.md:35 "from one to five minutes" for the whole static() call (JIT, verification and qiskit '
+                                            'post-processing included; hardware not stated)'}
+    except Exception as e:
+        out['config1'] = {'error': str(e)[:200]}
+    return out
 
 
 def executed_flops(variant, num_qubits, num_blocks, algorithmic):
@@ -154,6 +219,10 @@ def other_configs(workloads, TemplateEngine, torch, launches=3):
             if ex is not None:          # 'frac' prices SURVEY's dense-4x4 count; the ZYZ form executes fewer flops for the same result
                 rows[name]['flop_executed_per_sample_step'] = ex
                 rows[name]['frac_executed'] = rows[name]['frac'] * ex / eng.flops_per_sample_step
+            slots, _ = stored_issue_slots(name)
+            if slots:
+                rows[name].update(slots)
+                rows[name]['port_floor_frac'] = slots['port_floor_ms'] / ms if slots.get('port_floor_ms') else None
             eng.close()
         except Exception as e:          # reported, never required
             rows[name] = {'error': str(e)[:300]}
@@ -173,6 +242,23 @@ def stored_traffic(config, samples_per_gpu):
             continue
         if d.get('config', 'cfg2') == config and d.get('samples', 1024) == samples_per_gpu and d.get('traffic_bytes_per_launch'):
             return d['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def stored_issue_slots(config):
+    """What the configuration's kernel asks of a SIMD's vector port (tools/issue_slots.py: the static mix of the step loops scaled to
+    the counters' dynamic instruction count, priced at the placement-verified rates of tools/micro/issue_cost2.hip), from the newest
+    committed profiles/r*_issue_slots.json.  Returns (dict or None, file name or None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_issue_slots.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if config in d:
+            e = d[config]
+            return {k: e.get(k) for k in ('issue_slots_per_sample_step', 'port_cycles_per_sample_step', 'port_floor_ms', 'port_busy')}, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -230,11 +316,21 @@ def main():
     first, count = distributed.shard_range(S_total, rank, n_gpus)
     assert count == S_local
 
+    gather_ms = []                      # wall time of the ONE collective of a step, per timed step (N > 1)
+
     def step():
         init = eng.initial_angles(seed, S_total, first, count)
         out = eng.optimize(init)
+        if world > 1:
+            # the collective on its own clock: drain this rank's kernel first, so that launch skew between the ranks (the wait inside
+            # the all-gather for the slowest one) and the kernel's own time separate in the line (`distributed.per_rank`)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
         summary = distributed.gather_samples(
             {k: out[k] for k in ('regloss', 'loss', 'cz', 'passed')}, S_total)
+        if world > 1:
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - tg) * 1e3)
         return out, summary
 
     def fence():
@@ -247,6 +343,7 @@ def main():
         step()
     fence()
     eng.event_log = []                  # HIP events on the launch stream around every optimize kernel
+    gather_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -254,6 +351,7 @@ def main():
     elapsed = time.perf_counter() - t0
     k_ms, k_all = eng.mean_kernel_ms()  # average launch duration over the timed region
     eng.event_log = None
+    my_gather = list(gather_ms)
     out, summary = step()
     fence()
 
@@ -272,6 +370,7 @@ def main():
             strong_ref = {'samples': S_total, 'ms_per_step_one_gpu': (time.perf_counter() - t1) / 3 * 1e3, 'kernel': eng.last_variant()}
         dist.barrier()
 
+    local_elapsed = elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if world == 1 or dist.get_backend() == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,6 +379,19 @@ def main():
     # what torch.distributed saw: backend, world size, and the distinct devices behind the ranks (every rank contributes
     # its device's UUID / PCI bus id), so that a reader can tell N ranks on N devices from N ranks on one
     dist_info = distributed.describe_job(eng.device)
+    if world > 1:
+        # per rank: its own mean kernel time, its own mean time inside the collective (a rank that arrives early waits there for the
+        # slowest one) and its own wall time of the timed region - launch skew, RCCL latency and kernel time in one line
+        mine = {'rank': rank, 'kernel_ms': k_ms, 'collective_ms': sum(my_gather) / max(1, len(my_gather)),
+                'collective_ms_min': min(my_gather) if my_gather else None, 'collective_ms_max': max(my_gather) if my_gather else None,
+                'elapsed_ms_per_step': local_elapsed / args.steps * 1e3}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        dist_info['per_rank'] = per_rank
+        dist_info['collective'] = {'what': 'one all-gather per step of a [samples per rank, 6] float32 slab (regloss[2], loss[2], cz, passed: '
+                                           'cpflow_amd/distributed.py gather_samples), timed per rank around the call with the rank\'s own '
+                                           'kernel drained first',
+                                   'bytes_per_rank': int(S_local * 6 * 4)}
 
     if rank == 0:
         value = S_total * T * args.steps / elapsed
@@ -312,9 +424,17 @@ def main():
                     'frac': alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         ex = executed_flops(eng.last_variant(), wl.num_qubits, K, flops)
-        if ex is not None:
-            line['roofline']['flop_executed_per_sample_step'] = ex
-            line['roofline']['frac_executed'] = line['roofline']['frac'] * ex / flops
+        if ex is not None:          # what the kernel executes (the ZYZ form needs fewer flops than SURVEY's dense-4x4 count behind `frac`)
+            rf = line['roofline']
+            line['roofline'] = {'bound': rf['bound'], 'achieved': rf['achieved'], 'peak': rf['peak'], 'unit': rf['unit'], 'frac': rf['frac'],
+                                'frac_executed': rf['frac'] * ex / flops, 'flop_executed_per_sample_step': ex,
+                                **{k: v for k, v in rf.items() if k not in ('bound', 'achieved', 'peak', 'unit', 'frac')}}
+        slots, slots_src = stored_issue_slots(args.config)
+        if slots and S_local == wl.samples_per_gpu:
+            # the port's own view: instructions, not flops (stored, like `traffic`: counters need their own profiler passes)
+            line['roofline'].update(slots)
+            line['roofline']['port_floor_frac'] = slots['port_floor_ms'] / k_ms if slots.get('port_floor_ms') else None
+            line['roofline']['issue_slots_source'] = slots_src
         line['distributed'] = dist_info
         if strong_ref:
             # strong efficiency = t(1 GPU, all samples) / (N x t(N GPUs, all samples)); the weak one is the driver's from its per-N values

@@ -86,13 +86,11 @@ def precompile_shapes():
     conn3, chain3 = [[0, 1], [0, 2], [1, 2]], [[0, 1], [1, 2]]
     shapes += [(layer, 'xyz', K, 1000, 'cz') for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     # 3 qubits, the block counts an adaptive search over the reference's layers visits (tutorial/results/toff3_chain:
-    # 10..20): two-ended kernels specialised on the block count, which a launch picks up when it finds them (nothing
-    # compiles them at run time).  One per regime of samples per CU: one (<= 256 samples), two (both in one workgroup),
-    # a few with stored states (how many depends on K), saturated.  A few seconds of hipcc each.
-    shapes += [(layer, rot, K, S, 'cp', {'CPF_JIT_K': '1'}) for layer in (chain3, conn3) for rot in ('xyz', 'xz')
-               for K in range(6, 25) for S in (100, 400, 700, 2048, 8192)]
-    # ... and the 'cz' template runs above (1000 starts: a few samples per CU)
-    shapes += [(layer, 'xyz', K, 1000, 'cz', {'CPF_JIT_K': '1'}) for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
+    # 10..20): the two-ended ZYZ-form kernel (cpf_zyz3.h) is specialised on block count, cut and layer, and
+    # cpf_jit_precompile builds all three launch regimes' cuts of a shape whatever the sample count named here, so one
+    # entry per shape ships everything a launch of that shape can ask for (nothing compiles on a GPU box).  A few
+    # seconds of hipcc each.  (The 'cz' template shapes of the local-minimum study are in the list above.)
+    shapes += [(layer, rot, K, 1000, 'cp') for layer in (chain3, conn3) for rot in ('xyz', 'xz') for K in range(6, 25)]
     return shapes
 
 

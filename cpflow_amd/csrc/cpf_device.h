@@ -33,6 +33,22 @@ typedef long long int64_t;
 typedef unsigned long long uint64_t;
 #endif
 
+// The release library and its run-time built kernels know none of the timing-experiment / instrumentation switches of the
+// kernel headers ("wrong results by construction", cycle stamps that overwrite hist_loss, ...): without -DCPF_DIAGNOSTICS
+// (tools/gpu.py, cpflow_amd.build.build_variant('diag', ['CPF_DIAGNOSTICS', ...])) they are undefined here, whatever the
+// command line says.
+#ifndef CPF_DIAGNOSTICS
+#undef CPF_STAMPS
+#undef CPF_HWID
+#undef CPF_EXP_NORECLOAD
+#undef CPF_EXP_NOSWAP
+#undef CPF_EXP_NOGLOAD
+#undef CPF_EXP_NOREDUCE
+#undef CPF_EXP_NOBUILD
+#undef CPF_EXP_NOCHAIN
+#undef CPF_EXP_SWZ
+#endif
+
 namespace cpf {
 
 enum : int { OP_RX = 0, OP_RY = 1, OP_RZ = 2, OP_CP = 3, OP_CZ = 4, OP_CX = 5 };
@@ -566,6 +582,12 @@ __device__ __forceinline__ void fast_sincos(float x, float& sn, float& cn) {
     sn = __uint_as_float(__float_as_uint(s1) ^ (((unsigned)q & 2u) << 30));
     cn = __uint_as_float(__float_as_uint(c1) ^ ((((unsigned)q + 1u) & 2u) << 30));
 }
+// (m & a) | (~m & b) as one v_bfi_b32
+__device__ __forceinline__ unsigned z_bfi(unsigned m, unsigned a, unsigned b) {
+    unsigned o;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(o) : "v"(m), "v"(a), "v"(b));
+    return o;
+}
 // The same for two angles in one register pair: the reduction and both polynomials on v_pk_*_f32 (one instruction for both
 // angles), rounding / integer / select steps per half.  Per half the operations and their order are those of fast_sincos,
 // so the two give bit-identical results.
@@ -583,10 +605,14 @@ __device__ __forceinline__ void fast_sincos2(f2 x, f2& sn, f2& cn) {
     pc = pk_fma(pc, z, splat(4.166664568298827e-2f));
     const f2 c0 = pk_fma(pc, z * z, pk_fma(splat(-0.5f), z, splat(1.f)));
     const int qx = (int)k.x, qy = (int)k.y;
-    const bool ox = qx & 1, oy = qy & 1;
-    const float sx = ox ? c0.x : s0.x, cx = ox ? s0.x : c0.x, sy = oy ? c0.y : s0.y, cy = oy ? s0.y : c0.y;
-    sn = f2{__uint_as_float(__float_as_uint(sx) ^ (((unsigned)qx & 2u) << 30)), __uint_as_float(__float_as_uint(sy) ^ (((unsigned)qy & 2u) << 30))};
-    cn = f2{__uint_as_float(__float_as_uint(cx) ^ ((((unsigned)qx + 1u) & 2u) << 30)), __uint_as_float(__float_as_uint(cy) ^ ((((unsigned)qy + 1u) & 2u) << 30))};
+    // odd quadrant: sin and cos change places.  A bit-field select under the sign-extended parity bit (v_bfe_i32, v_bfi_b32: three
+    // instructions per half) instead of v_and / v_cmp / two v_cndmask and the two wait states between the compare and its readers
+    // (round 5's listing); the same bits either way.
+    const unsigned mx = (unsigned)__builtin_amdgcn_sbfe(qx, 0, 1), my = (unsigned)__builtin_amdgcn_sbfe(qy, 0, 1);
+    const unsigned s0x = __float_as_uint(s0.x), c0x = __float_as_uint(c0.x), s0y = __float_as_uint(s0.y), c0y = __float_as_uint(c0.y);
+    const unsigned sx = z_bfi(mx, c0x, s0x), cx = z_bfi(mx, s0x, c0x), sy = z_bfi(my, c0y, s0y), cy = z_bfi(my, s0y, c0y);
+    sn = f2{__uint_as_float(sx ^ (((unsigned)qx & 2u) << 30)), __uint_as_float(sy ^ (((unsigned)qy & 2u) << 30))};
+    cn = f2{__uint_as_float(cx ^ ((((unsigned)qx + 1u) & 2u) << 30)), __uint_as_float(cy ^ ((((unsigned)qy + 1u) & 2u) << 30))};
 }
 // LDS copy of the piece table: 8 lower break points (pieces 1..8), then 9 x (slope, intercept); 28 floats.
 // Selecting among kernel-argument fields made hipcc select the field ADDRESS and issue a per-lane global

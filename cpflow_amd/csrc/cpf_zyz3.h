@@ -71,7 +71,7 @@ constexpr int ZYZ3_ROW = 68;                     // floats per row of shares: 64
 __host__ __device__ constexpr int zyz3_lds_floats(int K) {
     const int rows = 10 + 7 * K, srows = 7 + 5 * K;
     const int pv = PEN_FLOATS + 8 * K + 4, tab = pv + 3 * ((K + 3) & ~3), surfm = tab + 16 * K, tot = surfm + 48 + 24, states = (tot + rows + 1 + 3) & ~3;
-    return states + 128 * 2 + srows * ZYZ3_ROW;
+    return states + 128 * 2 + 128 + srows * ZYZ3_ROW;
 }
 __host__ __device__ constexpr bool zyz3_supported(int K, int n_rot) { return K >= 2 && 2 * K <= 64 && n_rot >= 1 && n_rot <= 3; }
 
@@ -92,7 +92,8 @@ struct Zyz3Lds {                                  // float offsets, per sample; 
     static constexpr int CPT = MSF + 8;           // 4 x {k_t, k_u, k_d, -}: the CP angle's chain rule by (ca | cb << 1) (zyz::chain_cp as a table)
     static constexpr int TOT = CPT + 16;          // the ROWS sums, one spare slot behind them for stores that mean nothing
     static constexpr int STATES = up4(TOT + ROWS + 1);       // 2 x 64 x (re, im): the two states at the cut, psi(s_{M-1}) and W(s_{M-1})
-    static constexpr int PART = STATES + 128 * 2;            // SROWS x ZYZ3_ROW
+    static constexpr int SCR = STATES + 128 * 2;             // 2 x 64 floats nobody reads: where the row sums put what a row does not produce
+    static constexpr int PART = SCR + 128;                   // SROWS x ZYZ3_ROW
     static constexpr int TOTAL = PART + SROWS * ZYZ3_ROW;
     static constexpr int row_blk(int b) { return 10 + 7 * b; }
     static constexpr int srow_blk(int b) { return 7 + 5 * b; }
@@ -224,6 +225,37 @@ __device__ __forceinline__ void z3_partner3(f2 v, f2& p0, f2& p1, f2& p2) {
         "v_mov_b32_dpp %4, %6 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_mov_b32_dpp %5, %7 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
         : "=&v"(p0.x), "=&v"(p0.y), "=&v"(p1.x), "=&v"(p1.y), "=&v"(p2.x), "=&v"(p2.y) : "v"(v.x), "v"(v.y));
+}
+// One block of wave B's forward half in ONE statement: both stages un-applied from the working copy, which lives in the FIXED
+// registers v[2:3] (the only way to name a register pair AND its halves in one asm statement: the DPP stages take the halves, the
+// packed multiply the pair), then conj(d) x once into o (kept for the gradient half) and once back into the working copy.  One
+// statement per block instead of two: between two dependent asm statements the compiler inserts a wait state of its own, and the
+// tied halves of a free register pair made its allocator copy halves around (2 v_mov_b32 in every other block of round 6's first
+// listing).  The previous statement wrote v[2:3] with its last instruction: two wait states in front.
+template <int QA, int QB, bool LAST>
+__device__ __forceinline__ f2 z3_unapply_block(float& L0, float& L1, f2 d, float ta, float tb) {
+    static_assert(QA >= 0 && QA < 3 && QB >= 0 && QB < 3 && QA != QB, "row qubits 0 .. 2 sit on lane bits 0, 1, 3");
+    f2 o, t;
+#define CPF_Z3_BODY(TAIL, CA, CB)                                                                                            \
+    asm("s_nop 1\n\t"                                                                                                        \
+        "v_fmac_f32_dpp v2, v2, -%5 " CA CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%5 " CA CPF_Z3_DPPT                             \
+        "s_nop 0\n\t"                                                                                                        \
+        "v_fmac_f32_dpp v2, v2, -%6 " CB CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%6 " CB CPF_Z3_DPPT                             \
+        "v_pk_mul_f32 %1, %4, v[2:3] op_sel_hi:[0,1]\n\t"                                                                    \
+        "v_pk_fma_f32 %0, %4, v[2:3], %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" TAIL                               \
+        : "=&v"(o), "=&v"(t), "+{v2}"(L0), "+{v3}"(L1) : "v"(d), "v"(ta), "v"(tb));
+#define CPF_Z3_TAILED(CA, CB)                                                                                                \
+    if constexpr (LAST) { CPF_Z3_BODY("", CA, CB) }                                                                          \
+    else { CPF_Z3_BODY("\n\tv_pk_fma_f32 v[2:3], %4, v[2:3], %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]", CA, CB) }
+    if constexpr (QA == 0 && QB == 1) { CPF_Z3_TAILED(CPF_Z3_C0, CPF_Z3_C1) }
+    else if constexpr (QA == 0 && QB == 2) { CPF_Z3_TAILED(CPF_Z3_C0, CPF_Z3_C2) }
+    else if constexpr (QA == 1 && QB == 0) { CPF_Z3_TAILED(CPF_Z3_C1, CPF_Z3_C0) }
+    else if constexpr (QA == 1 && QB == 2) { CPF_Z3_TAILED(CPF_Z3_C1, CPF_Z3_C2) }
+    else if constexpr (QA == 2 && QB == 0) { CPF_Z3_TAILED(CPF_Z3_C2, CPF_Z3_C0) }
+    else { CPF_Z3_TAILED(CPF_Z3_C2, CPF_Z3_C1) }
+#undef CPF_Z3_TAILED
+#undef CPF_Z3_BODY
+    return o;
 }
 // The four products behind a block's Px / Py shares, halves of the live matrix v selected by op_sel (the compiler builds the
 // broadcast of v.y with a v_mov_b32 and then splits the register pair: two moves per block in round 5's listing):
@@ -363,9 +395,18 @@ __device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upp
     x = upper ? x1 : x0; y = upper ? y1 : y0; z = upper ? z1 : z0;
 }
 
+#ifndef CPF_Z3_ROWMASK
+#define CPF_Z3_ROWMASK 1         // A/B: 1 = the lanes without a row of shares sit the row sums out (exec mask) instead of adding a row again:
+                                 // fewer LDS reads and stores where four samples share a CU's LDS (config 2 4.20 -> 4.13 ms, config 3's share
+                                 // 4.18 -> 4.20, same box); the barrier count checks that the step loops stayed whole
+#endif
 #ifndef CPF_Z3_HWSINCOS
-#define CPF_Z3_HWSINCOS 1        // A/B: 1 = (cos, sin) on v_sin_f32 / v_cos_f32 behind a two-constant reduction to [-pi, pi] (max error 3.7e-7
-                                 // against fast_sincos2's 6e-8, profiles/r05_hw_sincos_accuracy.txt), 0 = the polynomials of cpf_device.h
+#define CPF_Z3_HWSINCOS 0        // A/B: 1 = (cos, sin) on v_sin_f32 / v_cos_f32 behind a two-constant reduction to [-pi, pi]: 37 vector
+                                 // instructions fewer per owner phase and wave, config 2 4.26 -> 4.15 ms, config 3's share 4.32 -> 4.19 (same
+                                 // box; round 5's "no gain" was an artefact of its A/B tool) - and NOT adopted: max error 3.7e-7 against
+                                 // fast_sincos2's 6e-8 (profiles/r05_hw_sincos_accuracy.txt) is a rounding of every ANGLE at the 1e-7 level,
+                                 // which Adam's first steps amplify: short trajectories left the envelope the float32 oracle itself stays
+                                 // in (test_short_adam_trajectory_matches_fp32_oracle 5.2e-5 against 3e-5, test_every_shipped_block_count)
 #endif
 __device__ __forceinline__ void z3_sincos2(f2 x, f2& sn, f2& cn) {
 #if CPF_Z3_HWSINCOS
@@ -379,6 +420,19 @@ __device__ __forceinline__ void z3_sincos2(f2 x, f2& sn, f2& cn) {
 #else
     fast_sincos2(x, sn, cn);
 #endif
+}
+struct Z3SideMap { int first[3], last[3]; };
+template <int K, int... UD>
+__host__ __device__ constexpr Z3SideMap z3_side_map() {
+    constexpr int LL = sizeof...(UD) / 2;
+    constexpr int ud[] = {UD...};
+    Z3SideMap m = {{-1, -1, -1}, {-1, -1, -1}};
+    for (int w = 0; w < 2 * K; w++) {
+        const int q = ud[2 * ((w >> 1) % LL) + (w & 1)];
+        if (m.first[q] < 0) m.first[q] = w;
+        m.last[q] = w;
+    }
+    return m;
 }
 // ROT: rotation string and entangler (cpf_blocks.h rot_pack / rot_with_ent); KC: blocks; MC: blocks of wave A (1 .. KC-1);
 // PAIRS: samples per workgroup (1 or 2); UD...: the layer (up0, dn0, up1, dn1, ...), block b sits on pair b mod len (topology.py:15-20).
@@ -468,7 +522,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     struct RowK { int row, d_tot, dz0, dz1, dz2, ds; float w01, w02, w12; };
     auto row_consts = [&](int r_lo, int r_hi, int r) {
         RowK k;
-        const int sr = r_lo + lane + 64 * r, none = Lds::TOT + Lds::ROWS;
+        // results a row does not produce go to a scratch slot of this lane's own (round 5 sent them all to ONE spare address: up to 45
+        // lanes of a store on one bank)
+        const int sr = r_lo + lane + 64 * r, none = Lds::SCR + (r_lo == 0 ? 0 : 64) + lane;
         k.row = sr < r_hi ? sr : r_hi - 1;
         k.d_tot = k.dz0 = k.dz1 = k.dz2 = k.ds = none;
         k.w01 = k.w02 = k.w12 = 0.f;
@@ -485,10 +541,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                     if (q == 0) k.dz0 = dst; else if (q == 1) k.dz1 = dst; else k.dz2 = dst;
                 } else k.d_tot = dst;
             } else {
-                int dz[3] = {none, none, none};
-                if (b < 0) { dz[0] = Lds::TOT + 2; dz[1] = Lds::TOT + 5; dz[2] = Lds::TOT + 8; }
-                else { dz[qubit_of(2 * b)] = Lds::TOT + Lds::row_blk(b) + 2; dz[qubit_of(2 * b + 1)] = Lds::TOT + Lds::row_blk(b) + 5; }
-                k.dz0 = dz[0]; k.dz1 = dz[1]; k.dz2 = dz[2];
+                if (b < 0) { k.dz0 = Lds::TOT + 2; k.dz1 = Lds::TOT + 5; k.dz2 = Lds::TOT + 8; }
+                else {                                       // (selects, not a dynamically indexed local array: no private segment)
+                    const int qu = qubit_of(2 * b), qd = qubit_of(2 * b + 1), du = Lds::TOT + Lds::row_blk(b) + 2, dd = Lds::TOT + Lds::row_blk(b) + 5;
+                    k.dz0 = qu == 0 ? du : (qd == 0 ? dd : none);
+                    k.dz1 = qu == 1 ? du : (qd == 1 ? dd : none);
+                    k.dz2 = qu == 2 ? du : (qd == 2 ? dd : none);
+                }
                 if (b + 1 < K) {                             // the |11> sum of the NEXT block's pair
                     k.ds = Lds::TOT + (b < 0 ? 9 : Lds::row_blk(b) + 6);
                     const int qa = qubit_of(2 * (b + 1)), qb = qubit_of(2 * (b + 1) + 1), pr = (1 << qa) | (1 << qb);
@@ -798,7 +857,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             }
             lds_fence();
 #pragma unroll
-            for (int r = 0; r < NRA; r++) row_sums(rka[r]);
+            for (int r = 0; r < NRA; r++) {
+#if CPF_Z3_ROWMASK
+                if (lane + 64 * r < SA) row_sums(rka[r]);
+#else
+                row_sums(rka[r]);
+#endif
+            }
             CPF_STAMP(5)                                  // gradient half + row sums
             barrier();
             CPF_STAMP(6)
@@ -834,9 +899,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     const int64_t os_idx = ovs ? os_raw : (int64_t)a.nsamples - 1;
     const float2 vt_ = a.target[row * 8 + col];
     const f2 vt = {vt_.x, vt_.y};
-    int lastside[3] = {-1, -1, -1}, firstside[3] = {-1, -1, -1};
-    for (int w = 2 * K - 1; w >= 0; w--) firstside[qubit_of(w)] = w;
-    for (int w = 0; w < 2 * K; w++) lastside[qubit_of(w)] = w;
+    // first / last side on each row qubit: compile-time constants of the layer and the block count
+    constexpr Z3SideMap sm = z3_side_map<K, UD...>();
+    const int lastside[3] = {sm.last[0], sm.last[1], sm.last[2]}, firstside[3] = {sm.first[0], sm.first[1], sm.first[2]};
     // S2: lanes 2 w and 2 w + 1 work for side w - the even one is its main lane (slots 0, 1 and everything else), the odd one owns slots 2, 3
     const int iw = S2 ? (il >> 1) : il;
     const bool odd2 = S2 && (il & 1);
@@ -984,13 +1049,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         f2 x, xs;                                            // W(s_b) as the gradient half will read it, and the copy the next block's stages overwrite
         z3_cmul_conj2(z3_cmul(f2{lf[2].x, lf[2].y}, z3_cmul(f2{lf[1].x, lf[1].y}, f2{lf[0].x, lf[0].y})), vt, x, xs);
         own[K - M] = x;
-        static_for([&](auto bb) __attribute__((always_inline)) {
-            constexpr int B = K - 1 - decltype(bb)::value, J = B % LL;
-            z3_stage2<PL::v[2 * J + 1], PL::v[2 * J], true>(xs, ent[B - M].w, ent[B - M].z);
-            if constexpr (B > M) z3_cmul_conj2(f2{ent[B - M].x, ent[B - M].y}, xs, x, xs);
-            else x = z3_cmul_conj(f2{ent[B - M].x, ent[B - M].y}, xs);
-            own[B - M] = x;                                                  // W(s_{B-1})
-        }, typename make_iseq<K - M>::type{});
+        {
+            float L0 = xs.x, L1 = xs.y;                      // the working copy, in v[2:3] inside every block's statement: see z3_unapply_block
+            static_for([&](auto bb) __attribute__((always_inline)) {
+                constexpr int B = K - 1 - decltype(bb)::value, J = B % LL;
+                x = z3_unapply_block<PL::v[2 * J + 1], PL::v[2 * J], B == M>(L0, L1, f2{ent[B - M].x, ent[B - M].y}, ent[B - M].w, ent[B - M].z);
+                own[B - M] = x;                                              // W(s_{B-1})
+            }, typename make_iseq<K - M>::type{});
+        }
         sp[64] = x;                                   // W(s_{M-1}): the only state the other wave reads
         CPF_STAMP(2)                                  // forward half
         barrier();
@@ -1040,7 +1106,13 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }
         lds_fence();
 #pragma unroll
-        for (int r = 0; r < NRB; r++) row_sums(rkb[r]);
+        for (int r = 0; r < NRB; r++) {
+#if CPF_Z3_ROWMASK
+            if (lane + 64 * r < SROWS - SA) row_sums(rkb[r]);
+#else
+            row_sums(rkb[r]);
+#endif
+        }
         CPF_STAMP(5)                                  // gradient half + row sums
         barrier();
         CPF_STAMP(6)

@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "../../include/cpflow_amd.h"
@@ -56,6 +57,12 @@ TuneVal tuning(const char* name) {
 #endif
     return v;
 }
+// switches that exist in a -DCPF_DIAGNOSTICS build only (the release library does not even hold their names)
+#ifdef CPF_DIAGNOSTICS
+#define CPF_DIAG_TUNING(name) tuning(name)
+#else
+#define CPF_DIAG_TUNING(name) TuneVal()
+#endif
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -310,7 +317,7 @@ bool launch_layered3_layer(const cpf_plan* plan, const cpf::KArgs& a, int64_t S,
     return false;
 }
 bool try_layered3_aot(const cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
-    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
+    { const TuneVal e = CPF_DIAG_TUNING("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: force the runtime build
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 ||
         plan->entangler != CPF_ENTANGLER_CP || plan->K < 1)
         return false;
@@ -353,7 +360,7 @@ int launch_layered_aot(const cpf_plan* plan, const cpf::KArgs& a_in, int K, int6
     return 0;
 }
 bool try_layered_big_aot(const cpf_plan* plan, const cpf::KArgs& a, int lw, int64_t S, hipStream_t stream, int* rc) {
-    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
+    { const TuneVal e = CPF_DIAG_TUNING("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }
     if (plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->n != plan->NQ || plan->entangler != CPF_ENTANGLER_CP ||
         plan->rot != "xyz")
         return false;
@@ -803,16 +810,18 @@ size_t zyz3_lds_request(const cpf_plan* plan, int64_t S, int pairs) {
     (void)S;
     const int64_t lds1 = (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 * pairs;
     int64_t res = 0;
-    { const TuneVal e = tuning("CPF_ZYZ3_RES"); if (e) res = atoi(e.s.c_str()); }
+    { const TuneVal e = CPF_DIAG_TUNING("CPF_ZYZ3_RES"); if (e) res = atoi(e.s.c_str()); }
     if (res <= 0 || res * lds1 > plan->lds_per_cu) return (size_t)lds1;
     return (size_t)std::max<int64_t>(lds1, (plan->lds_per_cu / res - 1024) & ~(int64_t)255);      // (not the whole share: a CU keeps a little LDS back)
 }
 cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<int>& ud) {
     cpf_jit::Spec spec{"cpf_zyz3.h", cpf_jit::body_expr("zyz3_body", {rot, K, M, pairs}, ud), 128 * pairs};
-    { const TuneVal e = tuning("CPF_ZYZ3_STAMPS"); if (e && e[0] == '1') spec.flags = {"-DCPF_STAMPS"}; }      // diagnostics: per-phase cycle sums (tools/gpu.py stamps)
+#ifdef CPF_DIAGNOSTICS
+    { const TuneVal e = CPF_DIAG_TUNING("CPF_ZYZ3_STAMPS"); if (e && e[0] == '1') spec.flags = {"-DCPF_DIAGNOSTICS", "-DCPF_STAMPS"}; }      // per-phase cycle sums (tools/gpu.py stamps)
     {   // A/B builds: extra -D flags, separated by spaces
-        const TuneVal e = tuning("CPF_ZYZ3_DEFS");
+        const TuneVal e = CPF_DIAG_TUNING("CPF_ZYZ3_DEFS");
         size_t i = 0;
+        if (e && spec.flags.empty()) spec.flags.push_back("-DCPF_DIAGNOSTICS");
         while (e && i < e.s.size()) {
             size_t j = e.s.find(' ', i);
             if (j == std::string::npos) j = e.s.size();
@@ -820,6 +829,7 @@ cpf_jit::Spec zyz3_jit_spec(int rot, int K, int M, int pairs, const std::vector<
             i = j + 1;
         }
     }
+#endif
     return spec;
 }
 // The kernel serves 3-qubit problems with 1..3 rotation letters, CP or CZ blocks, the |T|^2 losses and up to 32 blocks, and is the
@@ -833,19 +843,20 @@ bool zyz3_serves(const cpf_plan* plan, int mode, int loss_kind) {          // wh
     if (plan->layer_ud.empty() || plan->layer_ud.size() > 32) return false;
     return (int64_t)cpf::zyz3_lds_floats(plan->K) * 4 <= plan->lds_per_cu;
 }
-bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) {
-    if (!zyz3_serves(plan, a.mode, a.loss_kind)) return false;
+bool zyz3_selected() {                                                     // what the tuning switches say
     { const TuneVal e = tuning("CPF_ZYZ3"); if (e) return e[0] == '1'; }
-    for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_ZYZL", "CPF_JIT_K", "CPF_NO_AOT3"})
+    for (const char* other : {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_ZYZL", "CPF_JIT_K"})
         if (tuning(other)) return false;
+    if (CPF_DIAG_TUNING("CPF_NO_AOT3")) return false;
     return true;
 }
+bool zyz3_wanted(const cpf_plan* plan, const cpf::KArgs& a) { return zyz3_serves(plan, a.mode, a.loss_kind) && zyz3_selected(); }
 bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
     if (!zyz3_wanted(plan, a)) return false;
     const int M = zyz3_cut(plan, S), rot = dense_rot_code(plan), pairs = zyz3_pairs(plan, S);
     const size_t lds = zyz3_lds_request(plan, S, pairs);
     const std::string tail = " waves=2 K cut=" + std::to_string(M) + (pairs == 2 ? " pairs=2" : "");
-    const TuneVal defs = tuning("CPF_ZYZ3_DEFS"), stamps = tuning("CPF_ZYZ3_STAMPS");
+    const TuneVal defs = CPF_DIAG_TUNING("CPF_ZYZ3_DEFS"), stamps = CPF_DIAG_TUNING("CPF_ZYZ3_STAMPS");
     cpf::KArgs args = a;
     args.prio = zyz3_all_resident(plan, S);                  // every workgroup resident: wave B gets the higher issue priority
     { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
@@ -877,7 +888,7 @@ bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream
 // block count from the plan.  The tutorial's shape (chain_layer(3), 14 blocks, 100 samples): see DESIGN.md section 4.
 bool try_split3_cached_k(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream, int* rc) {
     if (!plan->use_jit || plan->force_generic || a.mode != cpf::MODE_OPTIMIZE || plan->NQ != 3 || plan->n != 3 || !kspec_enabled()) return false;
-    { const TuneVal e = tuning("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: the plain runtime build
+    { const TuneVal e = CPF_DIAG_TUNING("CPF_NO_AOT3"); if (e && e[0] == '1') return false; }      // A/B: the plain runtime build
     const int LL = (int)plan->layer_ud.size() / 2;
     if (plan->rot == "xyz" && plan->entangler == CPF_ENTANGLER_CP && ((LL == 2 && plan->K == 12) || (LL == 3 && plan->K == 16)) &&
         (plan->layer_ud == std::vector<int>{0, 1, 1, 2} || plan->layer_ud == std::vector<int>{0, 1, 0, 2, 1, 2}))
@@ -979,7 +990,7 @@ void fill_plan_shape(const cpf_problem* pb, cpf_plan* pl) {
     pl->P = 3 * pl->n + pl->nb * pl->K;
     pl->T = pb->num_iterations;
     pl->rot.assign(pb->rot_axes ? pb->rot_axes : "", (size_t)pb->n_rot);
-    { const TuneVal fg = tuning("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
+    { const TuneVal fg = CPF_DIAG_TUNING("CPF_FORCE_GENERIC"); pl->force_generic = fg && fg[0] == '1'; }
     { const TuneVal fj = tuning("CPF_JIT"); pl->use_jit = !(fj && fj[0] == '0'); }
     pl->NQ = pl->n < 3 ? 3 : pl->n;     // 2-qubit problems run as U (x) I on the 3-qubit kernel
     // Qubit relabelling (4 and 5 qubits, gate-by-gate kernel, one wave per sample).  That layout keeps the kernel's LAST
@@ -1033,9 +1044,16 @@ int32_t cpf_device_count(void) {
 const char* cpf_last_error(void) { return g_err; }
 
 int32_t cpf_set_tuning(const char* name, const char* value) {
+    // The release library knows the kernel-FAMILY switches only - what the parity tests need to put two families of one shape side by
+    // side.  Timing experiments and instrumented builds (phase stamps, extra -D flags handed to the run-time compiler, residency and
+    // forced-generic switches) exist in a library built with -DCPF_DIAGNOSTICS only (tools/gpu.py, cpflow_amd.build.build_variant).
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
-                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL", "CPF_FORCE_GENERIC",
-                                        "CPF_JIT", "CPF_JIT_K", "CPF_NO_AOT3", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS", "CPF_ZYZ3_RES", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS"};
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL",
+                                        "CPF_JIT", "CPF_JIT_K", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS",
+#ifdef CPF_DIAGNOSTICS
+                                        "CPF_FORCE_GENERIC", "CPF_NO_AOT3", "CPF_ZYZ3_RES", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS",
+#endif
+    };
     if (!name) return fail(-1, "cpf_set_tuning: name is NULL");
     for (const char* k : known)
         if (!strcmp(k, name)) {
@@ -1333,10 +1351,19 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     }
     // 3 qubits: the two-ended ZYZ-form kernel (cpf_zyz3.h), the default at every number of samples - then nothing else
     // is built for the shape: the gate-by-gate kernels that read the block count from the plan are part of the library
-    if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind)) {
-        const int M = zyz3_cut(&pl, num_samples), rot = dense_rot_code(&pl), pairs = zyz3_pairs(&pl, num_samples);
-        if (!cpf_zyz3_has_aot(rot, pl.K, M, pairs, pl.layer_ud)) {
-            const cpf_jit::Spec spec = zyz3_jit_spec(rot, pl.K, M, pairs, pl.layer_ud);
+    if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind) && zyz3_selected()) {
+        // every launch regime's cut (zyz3_cut: K / 2 at one sample per CU, 0.33 K while all workgroups are resident, 0.43 K in rounds),
+        // whatever `num_samples` says: which regime a launch falls into depends on the device's CU count and LDS size, and a
+        // cache built for one sample count must not make another one compile on the launch path.  CPF_ZYZ3_M, when
+        // set, names the one cut to build.
+        const int rot = dense_rot_code(&pl), pairs = zyz3_pairs(&pl, num_samples), K = pl.K;
+        std::vector<int> cuts = {K / 2, (33 * K + 50) / 100, (43 * K + 50) / 100};
+        if (tuning("CPF_ZYZ3_M")) cuts = {zyz3_cut(&pl, num_samples)};
+        std::set<int> seen;
+        for (int m : cuts) {
+            const int M = std::max(1, std::min(K - 1, m));
+            if (!seen.insert(M).second || cpf_zyz3_has_aot(rot, K, M, pairs, pl.layer_ud)) continue;
+            const cpf_jit::Spec spec = zyz3_jit_spec(rot, K, M, pairs, pl.layer_ud);
             const cpf_jit::Code code = cpf_jit::build(spec);
             if (code.bytes.empty()) return fail(-31, "precompile of %s failed: %s", spec.body.c_str(), code.error.c_str());
             if (int rc = precompile_landed(code, spec.body)) return rc;

@@ -138,9 +138,11 @@ int32_t cpf_unitary_device(const cpf_plan* plan, int64_t num_samples, const floa
 /* Duration in ms of the last cpf_optimize_device kernel of this plan, measured with HIP events
  * on the launch stream (blocks until that kernel has finished). */
 int32_t cpf_plan_last_kernel_ms(cpf_plan* plan, float* out_ms);
-/* Which kernel the last launch on this plan used: "split/aot ...", "zyz/aot waves=N", "zyzl/aot waves=1", "layered/aot waves=N",
- * "dense/aot waves=N", "<family>/jit(hipcc) ..." / "(hiprtc)" (runtime-specialised: the compiler that produced the code object,
- * whether it was built in this process or came from a cache) or "generic/aot waves=N (reason)". */
+/* Which kernel the last launch on this plan used: "<family>/<origin> <details>" with family zyz3 (3 qubits, two-ended ZYZ form:
+ * "zyz3/aot waves=2 K cut=4"), zyzl (4 / 5 qubits, one wave per sample), zyz (6 qubits, dense layout), split / layered / dense (the
+ * gate-by-gate and dense-block fall-backs) or generic ("generic/aot waves=N (reason)"), and origin aot (built into the library) or
+ * jit(hipcc) / jit(hiprtc) (runtime-specialised: the compiler that produced the code object, whether it was built in this process or
+ * came from a cache). */
 int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
 
 /* ---- runtime specialisation (no counterpart in the reference: jax.jit compiles on first call, optimization.py:361-363).
@@ -151,8 +153,12 @@ int32_t cpf_plan_last_variant(const cpf_plan* plan, char* buf, size_t size);
  * <library dir>/jit_cache).  Returns the number of kernels (>= 0; 0 = the shape runs on ahead-of-time kernels only) and
  * one line per kernel in buf, or a negative error code. */
 int32_t cpf_jit_compiles(void);
-/* Diagnostics hook, not part of what a cpflow binding needs: forces a kernel family / variant for tests and A/B measurements
- * (the names and their values are listed in tools/README.md; value NULL restores the default).  Process-wide and thread-safe;
+/* Test hook, not part of what a cpflow binding needs: forces a kernel FAMILY / layout for parity tests that put two families of one
+ * shape side by side (value NULL restores the default).  The release library knows exactly these names: CPF_SPLIT, CPF_PSTORE,
+ * CPF_MSTORE, CPF_KSPEC, CPF_PAIRS, CPF_LONE, CPF_PRIO, CPF_LW, CPF_GROUP, CPF_DENSE, CPF_DENSE_LW, CPF_DENSE_SPECIALISED,
+ * CPF_DENSE_FOLD, CPF_ZYZ, CPF_ZYZL, CPF_RELABEL, CPF_JIT, CPF_JIT_K, CPF_ZYZ3, CPF_ZYZ3_M, CPF_ZYZ3_PAIRS (values: tools/README.md).
+ * Timing experiments and instrumented kernels (phase stamps, extra compiler flags for run-time builds, forced generic kernel, ...)
+ * exist only in a library built with -DCPF_DIAGNOSTICS (tools/gpu.py).  Process-wide and thread-safe;
  * a plan reads the switches when it is created and at every launch, and caches what it derived from them (per-block tables),
  * so set them BEFORE creating the plan they should apply to.  The release library reads none of them from the environment.
  * Returns 0, or -1 for an unknown name. */

@@ -149,6 +149,27 @@ class Oracle:
             out['history_params'], out['history_loss'] = hp, hl
         return out
 
+    def run_simd(self, init, nthreads=None):
+        """The float32 run over 16 samples at a time (cpf_oracle_simd.h): bench.py's "port-simd" CPU baseline.  Same outputs as
+        run(init, np.float32) without history; raises NotImplementedError for what the SIMD build does not cover."""
+        init = np.ascontiguousarray(np.atleast_2d(init), dtype=np.float32)
+        S, P = init.shape[0], self.P
+        assert init.shape[1] == P
+        out = dict(params=np.empty((S, 2, P), dtype=np.float32), regloss=np.empty((S, 2), dtype=np.float32),
+                   loss=np.empty((S, 2), dtype=np.float32), reg=np.empty((S, 2), dtype=np.float32),
+                   cz=np.empty(S, dtype=np.int32), passed=np.empty(S, dtype=np.uint8))
+        if nthreads is None:
+            nthreads = self.lib.cpfo_max_threads()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        err = self.lib.cpfo_run_f32_simd(C.byref(self.pb), C.c_int32(S), p(init), p(out['params']), p(out['regloss']), p(out['loss']),
+                                         p(out['reg']), p(out['cz']), p(out['passed']), C.c_int32(int(nthreads)))
+        if err == -2:
+            raise NotImplementedError('the SIMD build covers cost_HST with CP / CZ blocks and no frozen mask only')
+        if err:
+            raise MemoryError('oracle workspace allocation failed')
+        out['passed'] = out['passed'].astype(bool)
+        return out
+
     def count_cz(self, theta, dtype=np.float32):
         sfx, _ = self._sfx(dtype)
         th = np.ascontiguousarray(theta, dtype=dtype)

@@ -189,3 +189,6 @@ int cpfo_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ f32, W samples at a time (bench.py's "port-simd" baseline) */
+#include "cpf_oracle_simd.h"

@@ -382,6 +382,13 @@ def test_bench_launches_its_own_ranks():
     # the line describes the job torch.distributed ran: here gloo, two ranks, both on the box's one GPU
     di = line['distributed']
     assert di['backend'] == 'gloo' and di['world_size'] == 2 and [e['rank'] for e in di['ranks']] == [0, 1] and di['distinct_devices'] == 1
+    # ... and separates, per rank, the kernel's own time, the time inside the ONE collective of a step (where a rank that arrives early
+    # waits for the slowest one) and the rank's wall time per step: launch skew, RCCL latency and kernel time in one line
+    pr = di['per_rank']
+    assert [e['rank'] for e in pr] == [0, 1] and di['collective']['bytes_per_rank'] == 256 * 6 * 4
+    for e in pr:
+        assert e['kernel_ms'] > 0 and 0 < e['collective_ms_min'] <= e['collective_ms'] <= e['collective_ms_max']
+        assert e['elapsed_ms_per_step'] >= e['kernel_ms'] and e['elapsed_ms_per_step'] <= line['ms_per_step'] * (1 + 1e-9)
     # --strong-ref: rank 0 also ran the whole job's 512 samples on its one GPU (the strong-scaling reference of the same line)
     sr = line['strong_ref']
     assert sr['samples'] == 512 and sr['ms_per_step_one_gpu'] > 0 and abs(sr['strong_scaling_efficiency'] - sr['ms_per_step_one_gpu'] / (2 * line['ms_per_step'])) < 1e-9

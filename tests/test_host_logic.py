@@ -28,6 +28,34 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.cpf_device_count() >= 0
 
 
+def test_release_library_knows_the_family_switches_only():
+    """cpf_set_tuning of the release build accepts exactly the kernel-family names include/cpflow_amd.h lists; the timing-experiment
+    and instrumentation switches (extra compiler flags for run-time builds, phase stamps that overwrite hist_loss, forced generic
+    kernel, residency) exist in a -DCPF_DIAGNOSTICS build only - the release .so does not even hold their names."""
+    from cpflow_amd import _ffi
+    lib = _ffi.lib()
+    header = open(os.path.join(ROOT, 'include', 'cpflow_amd.h')).read()
+    doc = header[header.index('The release library knows exactly these names:'):header.index('(values: tools/README.md)')]
+    release = sorted(set(re.findall(r'\bCPF_[A-Z0-9_]+\b', doc)))
+    assert release == sorted(['CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_GROUP', 'CPF_DENSE',
+                              'CPF_DENSE_LW', 'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_JIT', 'CPF_JIT_K',
+                              'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_PAIRS'])
+    for name in release:
+        assert lib.cpf_set_tuning(name.encode(), b'1') == 0 and lib.cpf_set_tuning(name.encode(), None) == 0, name
+    blob = open(_ffi.lib_path() if hasattr(_ffi, 'lib_path') else os.path.join(ROOT, 'cpflow_amd', 'libcpflow_amd.so'), 'rb').read()
+    for name in ('CPF_ZYZ3_DEFS', 'CPF_ZYZ3_STAMPS', 'CPF_ZYZ3_RES', 'CPF_FORCE_GENERIC', 'CPF_NO_AOT3', 'CPF_STAMPS', 'CPF_HWID', 'CPF_EXP_NOSWAP', 'CPF_ENV_TUNING'):
+        assert lib.cpf_set_tuning(name.encode(), b'1') == -1 and b'unknown switch' in lib.cpf_last_error(), name
+        assert name.encode() not in blob, name
+    # ... and the kernel headers drop the experiment macros unless CPF_DIAGNOSTICS is defined (run-time built kernels included)
+    dev = open(os.path.join(ROOT, 'cpflow_amd', 'csrc', 'cpf_device.h')).read()
+    guard = dev[dev.index('#ifndef CPF_DIAGNOSTICS'):dev.index('#endif', dev.index('#ifndef CPF_DIAGNOSTICS'))]
+    used = set()
+    for h in os.listdir(os.path.join(ROOT, 'cpflow_amd', 'csrc')):
+        if h.endswith('.h'):
+            used |= set(re.findall(r'#if(?:def|ndef)?\s+(?:defined\()?(CPF_EXP_[A-Z0-9_]+|CPF_STAMPS|CPF_HWID)', open(os.path.join(ROOT, 'cpflow_amd', 'csrc', h)).read()))
+    assert used and all(f'#undef {m}' in guard for m in used), used
+
+
 def test_abi_argument_validation_without_gpu():
     from cpflow_amd import _ffi
     lib = _ffi.lib()
@@ -264,27 +292,34 @@ def test_block_count_specialised_kernels_per_regime(tmp_path):
     cache = tmp_path / 'cache'                 # a checkout whose shipped cache was not built yet compiles them - here, not into ~/.cache
     cache.mkdir(mode=0o700)
 
-    def kernels(K, S):
+    def kernels(K, S, tuning=None):
         code = ("import json, sys; from cpflow_amd.build import _precompile_one; "
-                f"print(json.dumps(_precompile_one({chain3!r}, 'xyz', {K}, {S}, tuning={{'CPF_JIT_K': '1'}})))")
+                f"print(json.dumps(_precompile_one({chain3!r}, 'xyz', {K}, {S}, tuning={tuning!r})))")
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CPF_JIT_CACHE=str(cache)), capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr
         lines = json.loads(r.stdout.strip().splitlines()[-1])
-        return re.sub(r'jit\(\w+\)', 'jit(hipcc)', lines[0].replace('[built]', '[cached]')) if lines else ''
-    # round 5: every 3-qubit shape runs on the two-ended ZYZ-form kernel; block count, cut (= blocks of wave A) and samples per
-    # workgroup are template arguments: one sample per CU -> K / 2; more, all resident -> 0.33 K rounded; launches that run in rounds ->
-    # 0.43 K (cpflow_amd.hip zyz3_cut); two samples per workgroup are a switch only
-    assert kernels(14, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=7 [cached] cpf::zyz3_body<8451, 14, 7, 1, 0, 1, 1, 2>')
-    assert kernels(14, 512).startswith('zyz3/jit(hipcc) waves=2 K cut=5 [cached] cpf::zyz3_body<8451, 14, 5, 1, 0, 1, 1, 2>')
-    assert kernels(14, 700).startswith('zyz3/jit(hipcc) waves=2 K cut=5 [cached] cpf::zyz3_body<8451, 14, 5, 1, 0, 1, 1, 2>')
-    assert kernels(12, 8192) == ''                                                          # config 2's shape: built into the library
-    assert kernels(14, 8192).startswith('zyz3/jit(hipcc) waves=2 K cut=6 [cached] cpf::zyz3_body<8451, 14, 6, 1, 0, 1, 1, 2>')
-    assert kernels(20, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=10 [cached]')
-    assert kernels(24, 100).startswith('zyz3/jit(hipcc) waves=2 K cut=12 [cached]')         # 54 KB of LDS per sample
+        return [re.sub(r'jit\(\w+\)', 'jit(hipcc)', x.replace('[built]', '[cached]')) for x in lines]
+    # every 3-qubit shape runs on the two-ended ZYZ-form kernel; block count, cut (= blocks of wave A) and samples per workgroup are
+    # template arguments: one sample per CU -> K / 2; more, all resident -> 0.33 K rounded; launches that run in rounds -> 0.43 K
+    # (cpflow_amd.hip zyz3_cut).  Round 6: the precompile step builds ALL THREE cuts of a shape whatever the sample count says (which
+    # regime a launch falls into depends on the device), so a cache built for one sample count serves every launch of the shape.
+    for S in (100, 700, 8192):
+        got = kernels(14, S)
+        assert [x.split(' [cached] ')[0] for x in got] == ['zyz3/jit(hipcc) waves=2 K cut=7', 'zyz3/jit(hipcc) waves=2 K cut=5', 'zyz3/jit(hipcc) waves=2 K cut=6'], got
+        assert got[0].endswith('cpf::zyz3_body<8451, 14, 7, 1, 0, 1, 1, 2>'), got
+    assert kernels(12, 8192) == []                                                          # config 2's shape: all three cuts built into the library
+    assert [x.split(' [cached] ')[0] for x in kernels(24, 100)] == [f'zyz3/jit(hipcc) waves=2 K cut={m}' for m in (12, 8, 10)]      # 54 KB of LDS per sample
+    # the cuts a launch would ask for are among them (tests/zyz3_shape.py restates the host's rule)
+    import zyz3_shape
+    for K, S in ((14, 100), (14, 512), (14, 8192), (20, 100), (24, 1000)):
+        assert any(f' cut={zyz3_shape.cut(K, S)} ' in x for x in kernels(K, 1000)), (K, S)
+    # a switch that selects another 3-qubit family is honoured by the precompile step as it is by a launch
+    assert not any(x.startswith('zyz3/') for x in kernels(14, 100, {'CPF_ZYZ3': '0'})) and kernels(14, 100, {'CPF_ZYZ3': '0'})[0].startswith('split/')
+    assert kernels(14, 100, {'CPF_ZYZ3_M': '3'})[0].startswith('zyz3/jit(hipcc) waves=2 K cut=3 ')
     from cpflow_amd.build import precompile_shapes
-    ks = [s for s in precompile_shapes() if len(s) > 5 and s[5] == {'CPF_JIT_K': '1'}]
-    assert {s[2] for s in ks if s[4] == 'cp'} == set(range(6, 25)) and {s[3] for s in ks if s[4] == 'cp'} == {100, 400, 700, 2048, 8192}
-    assert {(s[2], s[3]) for s in ks if s[4] == 'cz'} == {(K, 1000) for K in range(2, 17, 2)}        # the 'cz' template study
+    three = [s for s in precompile_shapes() if max(max(p) for p in s[0]) == 2]
+    assert {s[2] for s in three if s[4] == 'cp'} == set(range(6, 25)) and all(len(s) == 5 for s in three)
+    assert {(s[2], s[3]) for s in three if s[4] == 'cz'} == {(K, 1000) for K in range(2, 17, 2)}        # the 'cz' template study
 
 
 def test_shear_and_rz_pair_identities():

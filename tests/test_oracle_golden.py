@@ -189,3 +189,26 @@ def test_known_answers_pin_the_custom_loss_branches(golden_dir, name, dtype):
     orc = Oracle(layer, K, target, 'xyz', r=r, loss_kind=kind)
     out = orc.run(orc.initial_angles(seed, S), dtype)
     check_known_answer(out['cz'][out['passed']], S, score, cz_ref, f'{name} {np.dtype(dtype).name}')
+
+
+
+@pytest.mark.parametrize('layer,K,rot,ent,penalty', [([[0, 1], [1, 2]], 12, 'xyz', 'cp', 'linear'), ([[0, 1], [0, 2], [1, 2]], 5, 'xz', 'cp', 'L1'),
+                                                  ([[1, 0], [2, 3], [0, 3]], 4, 'zyx', 'cz', 'linear')])
+def test_simd_build_of_the_float32_run_matches_the_scalar_build(layer, K, rot, ent, penalty):
+    """oracle/cpf_oracle_simd.h (bench.py's "port-simd" CPU baseline): the float32 run over 16 samples at a time performs the scalar
+    build's operations in the scalar build's order, so the two agree to what libmvec's sinf / cosf (<= 4 ulp) let Adam amplify over a
+    short run - and bit for bit where no trigonometric function separates them (initial angles, reg of the initial angles)."""
+    n = max(max(p) for p in layer) + 1
+    rng = np.random.default_rng(7)
+    a = rng.normal(size=(2 ** n, 2 ** n)) + 1j * rng.normal(size=(2 ** n, 2 ** n))
+    target, _ = np.linalg.qr(a)
+    orc = Oracle(layer, K, target, rot, entangler=ent, penalty=penalty, num_gd_iterations=30, r=0.004)
+    init = orc.initial_angles(5, 21)                      # two lane groups, the second one ragged
+    ref, got = orc.run(init, np.float32, nthreads=2), orc.run_simd(init, nthreads=2)
+    assert (got['params'][:, 0] == init).all() and (got['reg'][:, 0] == ref['reg'][:, 0]).all()
+    assert np.abs(got['regloss'][:, 0] - ref['regloss'][:, 0]).max() < 2e-6          # the loss of the initial angles
+    assert np.abs(got['regloss'][:, 1] - ref['regloss'][:, 1]).max() < 2e-4          # the best of 30 Adam steps
+    assert np.median(np.abs(got['params'][:, 1] - ref['params'][:, 1]).max(axis=1)) < 2e-3
+    assert (got['loss'] == got['regloss'] - got['reg']).all() and (got['cz'] == ref['cz']).mean() >= 0.9
+    with pytest.raises(NotImplementedError):
+        Oracle(layer, K, target, rot, entangler=ent, penalty=penalty, num_gd_iterations=3, loss_kind=2).run_simd(init)

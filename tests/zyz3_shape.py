@@ -7,8 +7,8 @@ NUM_CU, LDS_PER_CU = 256, 160 * 1024
 
 def lds_bytes(K):
     rows, srows, up4 = 10 + 7 * K, 7 + 5 * K, lambda x: (x + 3) & ~3
-    tot = 28 + 8 * K + 4 + 3 * up4(K) + 16 * K + 48 + 4
-    return 4 * (up4(tot + rows + 1) + 2 * 128 + srows * 68)
+    tot = 28 + 8 * K + 4 + 3 * up4(K) + 16 * K + 48 + 24
+    return 4 * (up4(tot + rows + 1) + 2 * 128 + 128 + srows * 68)
 
 
 def pairs(K, S):

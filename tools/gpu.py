@@ -58,7 +58,14 @@ def sync_tuning():
     handed over through cpf_set_tuning before every plan creation / launch."""
     from cpflow_amd import _ffi
     for k in TUNING:
-        _ffi.set_tuning(k, os.environ.get(k))
+        try:
+            _ffi.set_tuning(k, os.environ.get(k))
+        except Exception:
+            # a release library does not know the diagnostics switches (CPF_ZYZ3_DEFS, CPF_ZYZ3_STAMPS, CPF_FORCE_GENERIC, ...):
+            # build one with cpflow_amd.build.build_variant('diag', ['CPF_DIAGNOSTICS']) and select it with CPF_LIB
+            if os.environ.get(k) is not None:
+                raise SystemExit(f'{k} needs a library built with -DCPF_DIAGNOSTICS: python -c "from cpflow_amd import build; '
+                                 f'build.build_variant(\'diag\', [\'CPF_DIAGNOSTICS\'])" and CPF_LIB=cpflow_amd/libcpflow_amd.diag.so')
 
 
 def engine(cfg, T=None, **kw):
