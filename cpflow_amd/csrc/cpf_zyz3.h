@@ -395,6 +395,16 @@ __device__ __forceinline__ void half_sum3(float& x, float& y, float& z, bool upp
     x = upper ? x1 : x0; y = upper ? y1 : y0; z = upper ? z1 : z0;
 }
 
+#ifndef CPF_Z3_EXECMASK
+#define CPF_Z3_EXECMASK 1        // A/B: 1 = only the lanes that own something execute the owner phases (of wave A's 64 lanes 6 own a surface angle
+                                 // and K evaluate a penalty, of wave B's 4 K hold a side) - not for speed in cycles but for POWER: the launch
+                                 // runs into the board's power limit (~1000 W on this pool: once round 6 had made the step loops denser, sclk
+                                 // dipped from 2.4 to 2.0 - 2.2 GHz for three launches in every ten), and idle lanes computing garbage burn
+                                 // what useful ones burn.  Same box, 1400 back-to-back launches of config 2: 989 W, mean 4.16 ms (bimodal:
+                                 // 4.07 / 4.45) without; 954 W, 4.05 ms steady with (profiles/r06_cfg2_levers_ab.txt).  A plain `if` on the
+                                 // lane: setting EXEC by hand around the phases was tried first and is unsafe - the compiler peels the first
+                                 // iteration and then computes the main loop's invariants inside the narrowed stretch
+#endif
 #ifndef CPF_Z3_ROWMASK
 #define CPF_Z3_ROWMASK 1         // A/B: 1 = the lanes without a row of shares sit the row sums out (exec mask) instead of adding a row again:
                                  // fewer LDS reads and stores where four samples share a CU's LDS (config 2 4.20 -> 4.13 ms, config 3's share
@@ -745,12 +755,15 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         }, typename make_iseq<M>::type{});
         z3_lds_f* pb_surf = (z3_lds_f*)part;
         asm volatile("" : "+v"(pb_surf));
-        barrier();                                           // constant records of the set-up
+        // lanes 0 .. 5 own the surface angles, lanes 0 .. K-1 evaluate the penalty of a CP angle each: nobody else executes the owner phase
+        const bool owner_a = !CPF_Z3_EXECMASK || lane < ((ENT == 0 && a.use_reg && K > 6) ? K : 6);
+        barrier();                                           // constant records of the set-up (the first owner phase runs on all lanes: whatever
+                                                             // the compiler computes once, in front of the loop, must not see a narrowed mask)
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
         for (int it = 0; it < iters; it++) {
-            {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
+            if (owner_a) {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
                 const float* tot = smem + Lds::TOT + 3 * qa;
                 float gs[3] = {0.f, 0.f, 0.f};
                 if (it > 0) {
@@ -872,6 +885,16 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[k] = (float)stamp_sum[k];
 #endif
+#ifdef CPF_HWID
+        // diagnostics build (tools/micro/hwid3.py, keep_history, T >= 4): HW_ID / XCC_ID of the sample's two waves in place of the
+        // first four entries of its loss history - which waves share a SIMD
+        if (a.hist_loss && lane == 0 && live) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            a.hist_loss[s_idx * a.T + 0] = (float)(hw & 0xffff); a.hist_loss[s_idx * a.T + 1] = (float)(xcc & 0xf);
+        }
+#endif
         barrier();                                           // wave B's verdict on the last iterate is out
         if (smem[Lds::MSF + 4] != 0.f) bt01 = th01;
         put_best(smem + Lds::PART);
@@ -976,13 +999,38 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     float* const tab_dst = is_side ? osmem + Lds::TAB + 16 * ib + 8 * iside : osmem + Lds::PART + 256 + 8 * lane;
     const float* const psl_src = osmem + Lds::PSL + (has_cp ? ib : 0);
     static_assert(Lds::SROWS * ZYZ3_ROW >= 256 + 8 * 64, "scratch for the lanes without a table entry");
+    // the lanes with angles of a side: nobody else executes the chain rule and the owner phase
+    const bool owner_b = owner_wave && (!CPF_Z3_EXECMASK || is_owner);
     barrier();                                               // penalty table, constant records: written by wave A's lanes
 #ifdef CPF_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
+#ifdef CPF_HWID
+    unsigned long long clk0 = 0, rt0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
+#endif
     for (int it = 0; it < iters; it++) {
-        // ================= owner: Adam closes the previous step; (cos, sin); sides, parities, e-pairs, tables, surface matrices
-        if (owner_wave) {
+        // ================= owner: the chain rule of the step just closed (into the owners' registers), Adam, (cos, sin); sides, parities,
+        // e-pairs, tables.  At the TOP of the step, under one branch on the lane (the last statement in front of the loop's back edge
+        // stays a barrier: see the head of this file).
+        if (owner_b) {
+        if (it > 0) {
+            const float* tot = osmem + Lds::TOT;
+            const float px = tot[rowP], py = tot[rowP + 1], pz = tot[rowP + 2];
+            const float s11 = tot[row_s11], pzu = tot[row_pzu], pzd = tot[row_pzd];
+            const float4 kcp = *reinterpret_cast<const float4*>(osmem + Lds::CPT + 4 * cacb);
+            auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
+                const int k = (idx - 1) >> 1;
+                c = cs[k][0]; sn = cs[k][1]; kind = 0;
+            };
+            float gp[4] = {0.f, 0.f, 0.f, 0.f};
+            zyz::chain_side<ROT & 0xFFFF>(gp, px, py, pz, sd, rrec, NR, iside);
+            if (ENT == 0) gp[3] = fmaf(kcp.x, s11, fmaf(kcp.y, pzu, kcp.z * pzd));
+            if constexpr (S2) {                           // slots 2, 3 go to the odd lane beside the main lane
+                const float n2 = z3_nb(gp[2]), n3 = z3_nb(gp[3]);
+                g01 = odd2 ? f2{n2, n3} : f2{gp[0], gp[1]};
+            } else { g01 = f2{gp[0], gp[1]}; g23 = f2{gp[2], gp[3]}; }
+        }
         if (it > 0 && has_cp && a.use_reg) { if constexpr (S2) g01.y += psl; else g23.y += psl; }
         adam_sincos(it, ic<S2 ? 1 : 0>{}, sc01);
         if (ENT == 0 && a.use_reg) {                          // wave A evaluates the penalty of the CP angles: the angles, then the step counter it waits for
@@ -1117,30 +1165,25 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         barrier();
         CPF_STAMP(6)
 
-        // ================= chain rule, into the owners' registers
-        if (owner_wave) {
-            const float* tot = osmem + Lds::TOT;
-            const float px = tot[rowP], py = tot[rowP + 1], pz = tot[rowP + 2];
-            const float s11 = tot[row_s11], pzu = tot[row_pzu], pzd = tot[row_pzd];
-            const float4 kcp = *reinterpret_cast<const float4*>(osmem + Lds::CPT + 4 * cacb);
-            auto rrec = [&](int idx, float& c, float& sn, int& kind) __attribute__((always_inline)) {
-                const int k = (idx - 1) >> 1;
-                c = cs[k][0]; sn = cs[k][1]; kind = 0;
-            };
-            float gp[4] = {0.f, 0.f, 0.f, 0.f};
-            zyz::chain_side<ROT & 0xFFFF>(gp, px, py, pz, sd, rrec, NR, iside);
-            if (ENT == 0) gp[3] = fmaf(kcp.x, s11, fmaf(kcp.y, pzu, kcp.z * pzd));
-            if constexpr (S2) {                           // slots 2, 3 go to the odd lane beside the main lane
-                const float n2 = z3_nb(gp[2]), n3 = z3_nb(gp[3]);
-                g01 = odd2 ? f2{n2, n3} : f2{gp[0], gp[1]};
-            } else { g01 = f2{gp[0], gp[1]}; g23 = f2{gp[2], gp[3]}; }
-        }
         CPF_STAMP(7)
     }
 #ifdef CPF_STAMPS
     if (blockIdx.x == 0 && pair == 0 && lane == 0 && a.hist_loss) for (int k = 0; k < 8; k++) a.hist_loss[8 + k] = (float)stamp_sum[k];
 #endif
 
+#ifdef CPF_HWID
+    if (a.hist_loss && lane == 0 && (PAIRS == 1 || s_raw < a.nsamples)) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.hist_loss[s_idx * a.T + 2] = (float)(hw & 0xffff); a.hist_loss[s_idx * a.T + 3] = (float)(xcc & 0xf);
+        if (a.T >= 6) {                                      // shader clocks and 100 MHz ticks of this wave's step loops: the clock the launch ran at
+            unsigned long long clk1, rt1;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1), "=s"(rt1) :: "memory");
+            a.hist_loss[s_idx * a.T + 4] = (float)(clk1 - clk0); a.hist_loss[s_idx * a.T + 5] = (float)(rt1 - rt0);
+        }
+    }
+#endif
     // ---- epilogue (optimization.py:365-370, cp_utils.py:144-164): reg recompute, loss = regloss - reg, argmin, CZ count, entry-loss flag
     barrier();                                               // wave A takes the verdict on the last iterate
     if (owner_wave) put_best(osmem + Lds::PART);

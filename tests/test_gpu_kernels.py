@@ -563,6 +563,14 @@ def test_every_shipped_block_count(layer, rot, monkeypatch, tune):
         # there), so the bound on the worst sample skips starts with such a component; the median bound holds for all
         quiet = (np.abs(orc.loss_grad(init, np.float64)['grad']) > 1e-6).all(axis=1)
         assert err[:, 0].max() < 5e-6 and np.median(err.max(axis=1)) < 3e-5 and err[quiet].max(initial=0.0) < 5e-4 and err.max() < 1e-2, (K, v, err.max())
+        # ... and whatever path a sample takes, EVERY iterate it visits carries its own loss to rounding (the float64 oracle evaluated at
+        # the kernel's own angles): the tight bound that does not depend on the trajectory - a step loop out of step, or a best iterate
+        # mixed from two steps, shows here on any single sample (the 1e-2 ceiling above would not catch it)
+        hp = out['history_params'].reshape(-1, orc.P)
+        here = orc.loss_grad(hp, np.float64, with_grad=False)['regloss'].reshape(out['history_regloss'].shape)
+        assert np.abs(out['history_regloss'] - here).max() < 1e-5, (K, v, np.abs(out['history_regloss'] - here).max())
+        best = orc.loss_grad(out['params'][:, 1], np.float64, with_grad=False)['regloss']
+        assert np.abs(out['regloss'][:, 1] - best).max() < 1e-5 and all(any((out['params'][s, 1] == out['history_params'][s, t]).all() for t in range(6)) for s in range(3))
         # an angle whose gradient is at rounding level (1e-8) takes a noisy first step and nudges the others at the next one:
         # the float32 and float64 oracles differ by > 1e-4 on 1.1 % of these entries themselves (K = 14, 'xyz'), max 3e-3
         dp = np.abs(out['history_params'] - ref['history_params'])[:, :3]
