@@ -47,6 +47,13 @@ typedef unsigned long long uint64_t;
 #undef CPF_EXP_NOBUILD
 #undef CPF_EXP_NOCHAIN
 #undef CPF_EXP_SWZ
+#undef CPF_MARKS
+#endif
+// phase markers for the static listings (tools/phase_mix.py): an assembler comment, in -DCPF_DIAGNOSTICS -DCPF_MARKS builds only
+#ifdef CPF_MARKS
+#define CPF_MARK(name) asm volatile("; CPF_MARK " #name ::: "memory")
+#else
+#define CPF_MARK(name)
 #endif
 
 namespace cpf {

@@ -338,6 +338,15 @@ __device__ __forceinline__ int z3_nb(int v) { return __builtin_amdgcn_update_dpp
 #ifndef CPF_Z3_PRIO
 #define CPF_Z3_PRIO 1            // issue priority of wave B in launches whose workgroups are all resident (zyz3_body; 0 = never raised)
 #endif
+// per-phase issue priorities of the two waves (0 .. 3) in such launches, as three decimal digits: owner / build, forward half, loss +
+// gradient half.  A wave of one sample shares its SIMD with the other-role wave of another sample, both in the same phase: the wave the
+// pair's barrier waits for should be served first.
+#ifndef CPF_Z3_PRIO_A
+#define CPF_Z3_PRIO_A 0
+#endif
+#ifndef CPF_Z3_PRIO_B
+#define CPF_Z3_PRIO_B (111 * CPF_Z3_PRIO)
+#endif
 typedef float z3_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void z3_allsum(float& re, float& im, bool odd) {
 #if CPF_Z3_MFMA
@@ -507,6 +516,12 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             make_float4((ca == cb) ? -2.f : 2.f, cb ? 0.f : (ca ? 1.f : -1.f), ca ? 0.f : (cb ? 1.f : -1.f), 0.f);
     }
 
+    // phase PH (0 owner / build, 1 forward half, 2 loss + gradient half) begins: set the wave's issue priority where it changes
+    auto phase_prio = [&](auto code, auto ph) __attribute__((always_inline)) {
+        constexpr int C = decltype(code)::value, PH = decltype(ph)::value;
+        constexpr int d[3] = {(C / 100) % 10, (C / 10) % 10, C % 10};
+        if constexpr (d[PH] != d[(PH + 2) % 3]) { if (a.prio) __builtin_amdgcn_s_setprio(d[PH]); }
+    };
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
     // Every barrier a wave passes is counted (one scalar add); the two waves compare their counts after the last step and poison the
     // sample's results when they differ.  The step loops are only correct while the compiler keeps ONE barrier per phase and wave: a
@@ -762,7 +777,9 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
+        if (a.prio && CPF_Z3_PRIO_A / 100 != 0) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_A / 100) % 10);
         for (int it = 0; it < iters; it++) {
+            phase_prio(ic<CPF_Z3_PRIO_A>{}, ic<0>{});
             if (owner_a) {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
                 const float* tot = smem + Lds::TOT + 3 * qa;
                 float gs[3] = {0.f, 0.f, 0.f};
@@ -795,6 +812,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             CPF_STAMP(0)
             barrier();                                       // tables and surface matrices of this step
             CPF_STAMP(1)
+            phase_prio(ic<CPF_Z3_PRIO_A>{}, ic<1>{});
             float4 ent[M];
             f2 own[M + 1];
             const float4 msf = *reinterpret_cast<const float4*>(smem + Lds::MSF);
@@ -822,6 +840,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             CPF_STAMP(2)                                  // forward half
             barrier();
             CPF_STAMP(3)
+            phase_prio(ic<CPF_Z3_PRIO_A>{}, ic<2>{});
             const f2 w_c = sp[64];
             const f2 tt = z3_cmul_conj(w_c, x);              // T = sum conj(W) psi at the cut
             float tr = tt.x, ti = tt.y;
@@ -906,11 +925,11 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // =========================================================================================================================
     // wave B: blocks M .. K-1, and the owner of every block angle: lane w < 2 K owns side w (block w >> 1, side w & 1)
     // =========================================================================================================================
-#if CPF_Z3_PRIO
+#if CPF_Z3_PRIO_B
     // While every workgroup of the launch is resident (a.prio, set by the host) wave B gets the higher issue priority on the SIMD it
     // shares with a wave A of another sample (config 2, cut 4: 5.35 -> 4.74 ms; raising wave A's in its gradient half on top: 4.92).
     // In a launch of several rounds of workgroups the priority starves the other waves (2048 samples 11.6 -> 14.8 ms).
-    if (a.prio) __builtin_amdgcn_s_setprio(CPF_Z3_PRIO);
+    if (a.prio) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_B / 100) % 10);
 #endif
     // the owner wave and, in it, the sample and the item of this lane
     const bool owner_wave = pair == 0;
@@ -1010,6 +1029,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
 #endif
     for (int it = 0; it < iters; it++) {
+        phase_prio(ic<CPF_Z3_PRIO_B>{}, ic<0>{});
         // ================= owner: the chain rule of the step just closed (into the owners' registers), Adam, (cos, sin); sides, parities,
         // e-pairs, tables.  At the TOP of the step, under one branch on the lane (the last statement in front of the loop's back edge
         // stays a barrier: see the head of this file).
@@ -1081,6 +1101,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         CPF_STAMP(0)                                  // owner / build
         barrier();
         CPF_STAMP(1)
+        phase_prio(ic<CPF_Z3_PRIO_B>{}, ic<1>{});
 
         // ================= forward half: Vd = conj(dfin) V = W(s_{K-1}), then blocks K-1 .. M un-applied.  The table entries are read
         // once and serve both sweeps; the states stay in registers for the gradient half.
@@ -1109,6 +1130,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         CPF_STAMP(2)                                  // forward half
         barrier();
         CPF_STAMP(3)
+        phase_prio(ic<CPF_Z3_PRIO_B>{}, ic<2>{});
 
         // ================= loss: T = sum conj(W) psi at the cut (wave A forms the same T for its cotangent)
         const f2 psi_c = sp[0];

@@ -235,6 +235,42 @@ __device__ __forceinline__ void zl_product(f2 (&x)[L::E], f2 base, const F& fac)
     }, typename make_iseq<L::NRR>::type{});
 }
 
+// The step's three wave sums (Re T, Im T, penalty) returned wave-uniform.  ONE v_permlane32_swap folds the wave's halves for T -
+// lanes 0..31 then hold re(l) + re(l + 32), lanes 32..63 im(l - 32) + im(l) - so its four row stages and one row_bcast run on one
+// register (cpf_zyz3.h z3_allsum); the penalty's chain alternates with it, each filling one of the other's two DPP wait states:
+// 11 DPP instructions and 6 s_nop instead of the 18 + 15 of three wave_sum calls.  Fixed order: run-to-run deterministic.
+__device__ __forceinline__ void zl_wave_sum3(float& re, float& im, float& pen, bool with_pen) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(re), __float_as_uint(im), false, false);
+    float s = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+#define CPF_ZL_T " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if (with_pen) {
+        float p = pen;
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2]" CPF_ZL_T "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2]" CPF_ZL_T "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1]" CPF_ZL_T "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1]" CPF_ZL_T "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:4" CPF_ZL_T "v_add_f32_dpp %1, %1, %1 row_ror:4" CPF_ZL_T "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8" CPF_ZL_T "v_add_f32_dpp %1, %1, %1 row_ror:8" CPF_ZL_T "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"
+            : "+v"(s), "+v"(p));
+        pen = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2]" CPF_ZL_T "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1]" CPF_ZL_T "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:4" CPF_ZL_T "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8" CPF_ZL_T "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+            : "+v"(s));
+        pen = 0.f;
+    }
+#undef CPF_ZL_T
+    re = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 31));
+    im = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+}
+
 // Items: one per side (i = 2 b + side < 2 K), then one per qubit (i = 2 K + q).  Item i belongs to thread i mod THREADS of the
 // sample's 64 or 256, slot i / THREADS (NSLOT slots per lane, a template argument), and that lane OWNS the item's angles - a side's rotation angles (and, for side 0, the
 // block's CP angle), a qubit's three surface angles: Adam state, (cos, sin), the side's factors and the gradients the chain phase
@@ -279,14 +315,23 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     uint32_t toff_i = (uint32_t)(L::row_index(lane, 0) * L::D + col) * 8u;
     int lane_i = lane, col_i = col;
     const char* tbase = reinterpret_cast<const char*>(a.target);
+    // 4 qubits (4 amplitudes per lane): the lane's target elements stay in registers for the whole run (8 registers of a kernel that may
+    // use 256: two waves per SIMD at most) instead of four global loads in the loss and four more before the backward sweep of every step
+    constexpr bool TREG = E <= 4;
+    float2 treg[TREG ? E : 1];
+    if constexpr (TREG) {
+#pragma unroll
+        for (int e = 0; e < E; e++) treg[e] = *reinterpret_cast<const float2*>(tbase + (toff_i + (uint32_t)((L::row_index(0, e)) * L::D * 8)));
+    }
     auto target_at = [&](int e) __attribute__((always_inline)) {
-        return *reinterpret_cast<const float2*>(tbase + (toff_i + (uint32_t)((L::row_index(0, e)) * L::D * 8)));
+        if constexpr (TREG) return treg[e];
+        else return *reinterpret_cast<const float2*>(tbase + (toff_i + (uint32_t)((L::row_index(0, e)) * L::D * 8)));
     };
     penalty_table_init(smem, a, tid);
 
     // ---- the items of this lane
     struct Item {
-        float th[4], mm[4], vv[4], g[4], cs[4][2];     // angle k: rotation letter k (side) / surface angle k (qubit); k = 3: the CP angle (side 0)
+        float th[4], bt[4], mm[4], vv[4], g[4], nlr[4], cs[4][2];     // angle k; nlr: minus the learning rate, 0 for an absent or frozen angle: rotation letter k (side) / surface angle k (qubit); k = 3: the CP angle (side 0)
         int pj[4];                                     // parameter index, -1 = none
         bool frz[4];
         int kind;                                      // 0 = side, 1 = qubit, 2 = none
@@ -295,6 +340,11 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         int cacb; float d0, psl, pval;                 // side 0: where the CP phase sits, the block's scale, r * penalty slope, penalty
         int m;                                         // qubit: all flips on it
     } itm[NSLOT];
+    // One wave per sample and one item per lane (2 K + n <= 64: config 4): the flip bits of all sides are ONE ballot, which stays in
+    // scalar registers, and the masks of the later sides on the qubit (this item's and, for side 0, its block's other side's) in this
+    // lane's - the parities of build B are an AND and a bit count each, without the LDS round trip and the word loops of the general form.
+    constexpr bool ONE = WPS == 1 && NSLOT == 1;
+    unsigned long long flips_all = 0, mask_own = 0, mask_nb = 0;
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
         Item& t = itm[s];
@@ -303,7 +353,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         t.prev = -1; t.cacb = 0; t.d0 = 1.f; t.psl = 0.f; t.pval = 0.f; t.m = 0;
         t.sd = zyz::Side{};
 #pragma unroll
-        for (int k = 0; k < 4; k++) { t.pj[k] = -1; t.th[k] = 0.f; t.mm[k] = 0.f; t.vv[k] = 0.f; t.g[k] = 0.f; t.cs[k][0] = 1.f; t.cs[k][1] = 0.f; t.frz[k] = false; }
+        for (int k = 0; k < 4; k++) { t.pj[k] = -1; t.th[k] = 0.f; t.bt[k] = 0.f; t.nlr[k] = 0.f; t.mm[k] = 0.f; t.vv[k] = 0.f; t.g[k] = 0.f; t.cs[k][0] = 1.f; t.cs[k][1] = 0.f; t.frz[k] = false; }
         if (t.kind == 0) {
             const int b = i >> 1, side = i & 1;
 #pragma unroll
@@ -320,15 +370,20 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         for (int k = 0; k < 4; k++) {
             if (t.pj[k] >= 0) {
                 t.th[k] = init[t.pj[k]];
+                t.bt[k] = t.th[k];                     // the best iterate's angles stay with their owner until the run ends
                 t.frz[k] = frozen && frozen[t.pj[k]];
+                t.nlr[k] = t.frz[k] ? 0.f : -a.lr;
                 a.out_params[(s_idx * 2) * P + t.pj[k]] = t.th[k];
-                out_best[t.pj[k]] = t.th[k];
             }
         }
         // static structure other lanes need: {prev, -, later masks} per item
         if (t.kind != 2) {
             const ZyzSideInfo si = za.sides[i];
             int* st = reinterpret_cast<int*>(smem + lds.stat + 12 * i);
+            if constexpr (ONE) {
+                mask_own = si.later[0];
+                if (t.kind == 0 && (i & 1) == 0) mask_nb = za.sides[i + 1].later[0];
+            }
             st[0] = si.prev; st[1] = si.qubit;
             for (int k = 0; k < 4; k++) { st[4 + 2 * k] = (int)(si.later[k] & 0xffffffffull); st[5 + 2 * k] = (int)(si.later[k] >> 32); }
         }
@@ -340,7 +395,8 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         sd.t = s0.x; sd.sc = s0.y; sd.l0 = zyz::c2(s0.z, s0.w); sd.l1 = zyz::c2(s1.x, s1.y); sd.f = __float_as_int(s1.z); sd.m = 0;
         return sd;
     };
-    auto parity_of = [&](int i) {                      // flips of the sides item i's mask names
+    auto parity_of = [&](int i, bool neighbour = false) {            // flips of the sides item i's mask names (i: this lane's item or, neighbour, the next one)
+        if constexpr (ONE) return (int)(__popcll(flips_all & (neighbour ? mask_nb : mask_own)) & 1);
         const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(smem + lds.stat + 12 * i + 4);
         int n = 0;
         for (int k = 0; k < nw; k++) n += __popcll(fw[k] & mask[k]);
@@ -360,25 +416,32 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
-        const float2 bc = const_load_f2(a.bias, a.T > 0 ? (it > 0 ? it - 1 : 0) : 0);          // Adam closes the PREVIOUS step here
+        CPF_MARK(top);
+        // Adam closes the PREVIOUS step here; the reciprocals of its bias corrections come from the host (cpflow_amd.hip: ibias[t] = 1 / bias[t])
+        const float2 ibc = const_load_f2(a.ibias, a.T > 0 ? (it > 0 ? it - 1 : 0) : 0);
         asm volatile("" : "+v"(toff_i), "+v"(lane_i), "+v"(col_i));
         // ================= owner + build A: Adam on the gradients of the previous step, (cos, sin), the side's factors
-        const float ibc1 = __builtin_amdgcn_rcpf(bc.x), ibc2 = __builtin_amdgcn_rcpf(bc.y);
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) {
             Item& t = itm[s];
             bool flip = false;
             if (t.kind != 2) {
+                // Two angles per packed instruction and no branch on the slot: an absent or frozen angle has the step size 0 (nlr) and,
+                // at the first iterate, every gradient is 0 - m and v of such a slot move, its angle does not.  The same operations in
+                // the same order as the scalar form (optax 0.1.1 scale_by_adam, optimization.py:61-75).
+                if (it > 0) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (t.pj[k] < 0) continue;
-                    if (it > 0 && !t.frz[k]) {
-                        float g = t.g[k];
-                        if (k == 3 && a.use_reg) g += t.psl;
-                        const float m = fmaf(a.b1, t.mm[k], a.omb1 * g);
-                        const float v = fmaf(a.b2, t.vv[k], a.omb2 * (g * g));
-                        t.mm[k] = m; t.vv[k] = v;
-                        t.th[k] = fmaf(-a.lr, (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + a.eps), t.th[k]);
+                    for (int h = 0; h < 2; h++) {
+                        f2 g = {t.g[2 * h], t.g[2 * h + 1]};
+                        if (h == 1 && ENT == 0 && a.use_reg) g.y += t.psl;
+                        const f2 m = pk_fma(splat(a.b1), f2{t.mm[2 * h], t.mm[2 * h + 1]}, splat(a.omb1) * g);
+                        const f2 v = pk_fma(splat(a.b2), f2{t.vv[2 * h], t.vv[2 * h + 1]}, splat(a.omb2) * (g * g));
+                        t.mm[2 * h] = m.x; t.mm[2 * h + 1] = m.y; t.vv[2 * h] = v.x; t.vv[2 * h + 1] = v.y;
+                        const f2 hh = v * splat(ibc.y);
+                        const f2 d = f2{__builtin_amdgcn_sqrtf(hh.x), __builtin_amdgcn_sqrtf(hh.y)} + splat(a.eps);
+                        const f2 u = (m * splat(ibc.x)) * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                        const f2 th = pk_fma(f2{t.nlr[2 * h], t.nlr[2 * h + 1]}, u, f2{t.th[2 * h], t.th[2 * h + 1]});
+                        t.th[2 * h] = th.x; t.th[2 * h + 1] = th.y;
                     }
                 }
                 {   // (cos, sin) of the four angles on packed arithmetic, two per call (bit-identical to fast_sincos per half); slot 3
@@ -410,9 +473,11 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 }
             }
             const unsigned long long bits = __builtin_amdgcn_ballot_w64(flip);
-            if (lane == 0) fw[s * WPS + wave] = bits;
+            if constexpr (ONE) flips_all = bits;
+            else if (lane == 0) fw[s * WPS + wave] = bits;
         }
         lds_sync<WPS>();
+        CPF_MARK(buildB);
         // ================= build B: pending-flip parities; side 0: the block's table; qubit: surface matrix, final left factor
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) {
@@ -423,7 +488,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 if ((i & 1) == 0) {
                     const int b = i >> 1;
                     zyz::Side sd = load_side(i + 1), pu = t.sd, pd = sd;
-                    sd.m = parity_of(i + 1);
+                    sd.m = parity_of(i + 1, true);
                     const int wu = t.prev, wd = reinterpret_cast<const int*>(smem + lds.stat + 12 * (i + 1))[0];
                     if (wu >= 0) { pu = load_side(wu); pu.m = t.sd.m ^ t.sd.f; }
                     if (wd >= 0) { pd = load_side(wd); pd.m = sd.m ^ sd.f; }
@@ -449,6 +514,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
         lds_sync<WPS>();
 
+        CPF_MARK(surface);
         // ================= forward: the (flipped) product state of the surface gates, then the blocks
         {
             auto sfac = [&](int q, int r) __attribute__((always_inline)) {
@@ -464,14 +530,22 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
             }, typename make_iseq<L::NLR>::type{});
             zl_product<L>(psi, base, sfac);
         }
+        CPF_MARK(fwd);
         {
             int b = 0;
             ZlRaw nxt;
-            zl_load_raw<L, PL::v[0], PL::v[1]>(nxt, smem + lds.btab, ln);
+            // The table the next read takes: a running address (one add per layer, the blocks of a layer at immediate offsets) instead of
+            // a clamped block index per read (s_cmp, s_cselect, s_mulk, s_add, v_mov: 5 of a forward block's 45 instructions).  The read
+            // behind the last block takes the 20 floats that follow the tables (the surface matrices: inside the sample's LDS) and is
+            // never used.
+            const float* btn = smem + lds.btab;
+            zl_load_raw<L, PL::v[0], PL::v[1]>(nxt, btn, ln);
+            btn += ZYZL_TAB_FLOATS;
             auto fwd_step = [&](auto jj) __attribute__((always_inline)) {
                 constexpr int J = decltype(jj)::value, JN = (J + 1) % LL;
                 const ZlRaw cur = nxt;
-                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * (b + 1 < K ? b + 1 : b), ln);
+                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, btn, ln);
+                btn += ZYZL_TAB_FLOATS;
                 __builtin_amdgcn_sched_barrier(0);               // the reads stay here (the scheduler would sink them to their first use)
                 ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
                 zl_use(t, cur, ln);
@@ -483,6 +557,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
             static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); }, typename make_iseq<LL>::type{});
         }
 
+        CPF_MARK(loss);
         // ================= loss and penalty; the final diagonal meets the target: Vd = conj(dfin) V in the cotangent's registers
         float acc[3] = {0.f, 0.f, 0.f};
         if (a.loss_kind == 2) {
@@ -517,8 +592,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 #pragma unroll
             for (int s = 0; s < NSLOT; s++) acc[2] += itm[s].pval;
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++) acc[k] = wave_sum(acc[k]);
+        zl_wave_sum3(acc[0], acc[1], acc[2], a.use_reg != 0);
         if constexpr (WPS > 1) {                 // fixed order: deterministic
             lds_sync<WPS>();
             if (lane == 0) { red[wave * 3] = acc[0]; red[wave * 3 + 1] = acc[1]; red[wave * 3 + 2] = acc[2]; }
@@ -526,6 +600,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { float sum = 0.f; for (int w = 0; w < WPS; w++) sum += red[w * 3 + k]; acc[k] = sum; }
         }
+        CPF_MARK(track);
         const float tr = acc[0], ti = acc[1];
         const float ab = sqrtf(fmaf(tr, tr, ti * ti));
         const float loss = (a.loss_kind == 2) ? 1.f - tr * a.inv_dim2 : 1.f - ab * ab * a.inv_dim2;
@@ -534,21 +609,24 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         bool improved = false;
         if (it == 0) { first = regloss; best = regloss; }
         else if (regloss < best) { best = regloss; improved = true; }
-        if (improved || a.hist_params) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) itm[s].bt[k] = improved ? itm[s].th[k] : itm[s].bt[k];       // a select, not a store per improvement
+        if (a.hist_params) {
 #pragma unroll
             for (int s = 0; s < NSLOT; s++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int j = itm[s].pj[k];
-                    if (j < 0) continue;
-                    if (improved) out_best[j] = itm[s].th[k];
-                    if (a.hist_params) a.hist_params[(s_idx * a.T + it) * P + j] = itm[s].th[k];
+                    if (j >= 0) a.hist_params[(s_idx * a.T + it) * P + j] = itm[s].th[k];
                 }
         }
         if (a.hist_loss && tid == 0) a.hist_loss[s_idx * a.T + it] = regloss;
         if (a.T == 0) break;
         if (it + 1 == iters) break;                    // the last step's gradient would move the angles past the last evaluated iterate
 
+        CPF_MARK(bwdinit);
         // ================= backward
         if (a.loss_kind == 2) {
 #pragma unroll
@@ -561,26 +639,34 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 #pragma unroll
             for (int e = 0; e < E; e++) cot[e] = zl_cmul(f, cot[e]);
         }
+        CPF_MARK(bwd);
         {
             int b = K - 1;
             ZlRaw nxt;
+            // running addresses here too; the read in front of block 0 takes the 20 floats before the tables (static structure: inside
+            // the sample's LDS) and is never used
+            const float* btn = smem + lds.btab + ZYZL_TAB_FLOATS * b;
+            float* sums_b = sums_w + 32 * b;
             {
                 const int jt = (K - 1) % LL;                     // the last block's layer position
                 static_for([&](auto jj) __attribute__((always_inline)) {
                     constexpr int J = decltype(jj)::value;
-                    if (J == jt) zl_load_raw<L, PL::v[2 * J], PL::v[2 * J + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * b, ln);
+                    if (J == jt) zl_load_raw<L, PL::v[2 * J], PL::v[2 * J + 1]>(nxt, btn, ln);
                 }, typename make_iseq<LL>::type{});
+                btn -= ZYZL_TAB_FLOATS;
             }
             auto bwd_step = [&](auto jj) __attribute__((always_inline)) {
                 constexpr int J = LL - 1 - decltype(jj)::value, JN = (J + LL - 1) % LL;
                 const ZlRaw cur = nxt;
-                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, smem + lds.btab + ZYZL_TAB_FLOATS * (b > 0 ? b - 1 : 0), ln);
+                zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, btn, ln);
+                btn -= ZYZL_TAB_FLOATS;
                 __builtin_amdgcn_sched_barrier(0);
                 ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
                 zl_use(t, cur, ln);
                 float d8[8];
                 zl_bwd<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, cot, t, ln, d8);
-                reduce8_rows<true>(d8, sums_w + 32 * b, lane, dst_lane);
+                reduce8_rows<true>(d8, sums_b, lane, dst_lane);
+                sums_b -= 32;
                 gate_fence<L>();
                 b--;
             };
@@ -591,6 +677,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
             }, typename make_iseq<LL>::type{});
             for (int full = K / LL; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
         }
+        CPF_MARK(gsurf);
         {   // generator sums of every qubit at the surface state
             float ds[8 * NBATCH];
 #pragma unroll
@@ -627,6 +714,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
         }
         lds_sync<WPS>();
 
+        CPF_MARK(chain);
         // ================= chain: the gradients of the item's own angles, into the owner's registers
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) {
@@ -663,6 +751,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 for (int k = 0; k < 3; k++) t.g[k] = gs[k];
             }
         }
+        CPF_MARK(end);
         // one wave: no barrier - the next step's owner phase reads only this lane's registers.  Several waves: another wave may still be
         // reading the side records / static structure this wave's owner phase is about to overwrite
         if constexpr (WPS > 1) lds_sync<WPS>();
@@ -674,9 +763,11 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (itm[s].pj[k] >= 0) out_best[itm[s].pj[k]] = itm[s].bt[k];
         const int j = itm[s].pj[3];
         if (j >= 0) {
-            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j], t1 = out_best[j];
+            const float t0 = a.out_params[(s_idx * 2 + 0) * P + j], t1 = itm[s].bt[3];
             float sl;
             if (a.use_reg) { acc[0] += penalty_lds(smem, a.pen_kind, t0, sl); acc[1] += penalty_lds(smem, a.pen_kind, t1, sl); }
             acc[2] += cz_value(bi ? t1 : t0, a.thr_cp);

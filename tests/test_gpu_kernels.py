@@ -31,6 +31,20 @@ CASES = [
 ]
 
 
+def _first_steps_within_float32(out, ref, orc, init, n=4):
+    """The first two iterates of samples 0 .. n-1 against the float64 run: 3e-5 per angle - plus what float32 allows an angle whose
+    gradient is itself of the size of float32's rounding.  Adam's first step is lr * g / (|g| + eps) (optax 0.1.1 scale_by_adam with
+    bias correction, optimization.py:61-75): an absolute gradient error dg moves the angle by lr * eps * dg / (|g| + eps)^2, which for
+    |g| ~ 1e-6 and the dg = 3e-8 of a float32 sum of 64 terms of size 1e-2 is 1e-5 .. 1e-4 (measured: tools/micro/first_step_dev.py,
+    gpurun_out/r06_first_step_dev.log - the float32 ORACLE leaves the float64 one by 8e-6 at an angle with g = -4.5e-7, a kernel with
+    another summation order by 3.9e-5).  For |g| > 1e-4 the allowance is below 3e-7: the bound stays 3e-5 where it meant something."""
+    g = np.abs(orc.loss_grad(init[:n], np.float64)['grad'])
+    lr, eps, dg = orc.pb.lr, orc.pb.eps, 3e-8
+    tol = 3e-5 + lr * eps * dg / (g + eps) ** 2
+    dev = np.abs(out['history_params'] - ref['history_params'])[:n, :2]
+    assert (dev <= tol[:, None, :]).all(), (dev.max(), np.argwhere(dev > tol[:, None, :])[:5])
+
+
 def _engine(layer, K, target, rot, **kw):
     from cpflow_amd.engine import TemplateEngine
     return TemplateEngine(layer, K, target, rot, **kw)
@@ -803,7 +817,7 @@ def test_zyz_form_kernel_matches_oracle(layer, K, rot, ent, lw, how, tune):
     assert eng.last_variant() == {'aot': 'zyz/aot', 'jit': 'zyz/jit(hipcc)'}[how] + f' waves={waves}', eng.last_variant()
     ref = orc.run(init, np.float64, keep_history=True)
     assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6       # loss at the initial angles
-    assert np.abs(out['history_params'] - ref['history_params'])[:4, :2].max() < 3e-5          # = the first gradient (Adam's first step is lr * sign-like)
+    _first_steps_within_float32(out, ref, orc, init)             # = the first gradient (Adam's first step is lr * sign-like)
     assert np.abs(out['history_regloss'] - ref['history_loss'])[:4].max() < 2e-5
     assert np.abs(out['history_params'] - ref['history_params'])[:4].max() < 2e-4
     # the degenerate starts sit on points where gradients vanish exactly in exact arithmetic: Adam's first step is then decided by
@@ -898,7 +912,7 @@ def test_zyz_form_on_the_gate_by_gate_layout_matches_oracle(layer, K, rot, ent, 
     assert eng.last_variant().startswith({'aot': 'zyzl/aot', 'jit': 'zyzl/jit(hipcc)'}[how] + ' waves=1'), eng.last_variant()
     ref = orc.run(init, np.float64, keep_history=True)
     assert np.abs(out['history_regloss'][:, 0] - ref['history_loss'][:, 0]).max() < 5e-6
-    assert np.abs(out['history_params'] - ref['history_params'])[:4, :2].max() < 3e-5
+    _first_steps_within_float32(out, ref, orc, init)
     assert np.abs(out['history_regloss'] - ref['history_loss'])[:4].max() < 2e-5
     assert np.abs(out['history_params'] - ref['history_params'])[:4].max() < 2e-4
     for s in (4, 5):
