@@ -106,26 +106,58 @@ __device__ __forceinline__ void zl_use(ZlTab<L, UP, DN>& t, const ZlRaw& r, cons
 #pragma unroll
     for (int k = 0; k < T::NPH; k++) { t.ph[k] = r.ph[k]; t.pn[k] = r.pn[k]; }
 }
-// one unnormalised stage on qubit Q: (a, b) <- (a - t b, b + t a); t arrives signed for a lane qubit
-template <class L, int Q>
+// A lane qubit's stage on two amplitudes: x += (+-t) x[partner], four v_fmac_f32_dpp whose DPP operand is the destination itself.
+// (Written in C++ the compiler does not fold a DPP read into an accumulate onto the register it reads: it emitted v_mov_b32_dpp +
+// v_fma_f32, four issue slots per amplitude instead of two - 16 of the 45 vector instructions of a forward block with a lane qubit.)
+// quad_perm / row_ror move within a row of 16 lanes, which one pass of the instruction reads before it writes.  s_nop 1: the
+// amplitudes may come straight from a vector write (two wait states before a DPP read).
+#ifndef CPF_ZL_INPLACE
+#define CPF_ZL_INPLACE 1         // A/B: 0 = the compiler's v_mov_b32_dpp + v_fma_f32
+#endif
+template <int BIT, bool NEG>
+__device__ __forceinline__ void zl_stage_lane2(f2& x0, f2& x1, float t) {
+    static_assert(BIT == 0 || BIT == 1 || BIT == 3, "lane bits one DPP control reaches");
+#define CPF_ZL_ST(CTRL, SGN)                                                                                                 \
+    asm("s_nop 1\n\t"                                                                                                        \
+        "v_fmac_f32_dpp %0, %0, " SGN "%4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                              \
+        "v_fmac_f32_dpp %1, %1, " SGN "%4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                              \
+        "v_fmac_f32_dpp %2, %2, " SGN "%4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                              \
+        "v_fmac_f32_dpp %3, %3, " SGN "%4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                   \
+        : "+v"(x0.x), "+v"(x0.y), "+v"(x1.x), "+v"(x1.y) : "v"(t));
+#define CPF_ZL_STS(CTRL) if constexpr (NEG) { CPF_ZL_ST(CTRL, "-") } else { CPF_ZL_ST(CTRL, "") }
+    if constexpr (BIT == 0) { CPF_ZL_STS("quad_perm:[1,0,3,2]") }
+    else if constexpr (BIT == 1) { CPF_ZL_STS("quad_perm:[2,3,0,1]") }
+    else { CPF_ZL_STS("row_ror:8") }
+#undef CPF_ZL_STS
+#undef CPF_ZL_ST
+}
+// one unnormalised stage on qubit Q: (a, b) <- (a - t b, b + t a) (NEG: the inverse, t -> -t); t arrives signed for a lane qubit
+template <class L, int Q, bool NEG = false>
 __device__ __forceinline__ void zl_stage(f2 (&x)[L::E], float t) {
     if constexpr (L::row_on_lane(Q)) {
         constexpr int BIT = L::row_bit(Q);
+        if constexpr (CPF_ZL_INPLACE != 0 && (BIT == 0 || BIT == 1 || BIT == 3) && L::E >= 2) {
 #pragma unroll
-        for (int e = 0; e < L::E; e++) {
-            const float px = xor_lane<BIT>(x[e].x), py = xor_lane<BIT>(x[e].y);
-            x[e].x = fmaf(t, px, x[e].x);
-            x[e].y = fmaf(t, py, x[e].y);
+            for (int e = 0; e < L::E; e += 2) zl_stage_lane2<BIT, NEG>(x[e], x[e + 1], t);
+        } else {
+            const float ts = NEG ? -t : t;
+#pragma unroll
+            for (int e = 0; e < L::E; e++) {
+                const float px = xor_lane<BIT>(x[e].x), py = xor_lane<BIT>(x[e].y);
+                x[e].x = fmaf(ts, px, x[e].x);
+                x[e].y = fmaf(ts, py, x[e].y);
+            }
         }
     } else {
         constexpr int BIT = L::row_bit(Q);
+        const float ts = NEG ? -t : t;
 #pragma unroll
         for (int e0 = 0; e0 < L::E; e0++) {
             if (e0 & (1 << BIT)) continue;
             const int e1 = e0 | (1 << BIT);
             const f2 a = x[e0], b = x[e1];
-            x[e0] = pk_fma(splat(-t), b, a);
-            x[e1] = pk_fma(splat(t), a, b);
+            x[e0] = pk_fma(splat(-ts), b, a);
+            x[e1] = pk_fma(splat(ts), a, b);
         }
     }
 }
@@ -198,17 +230,17 @@ __device__ __forceinline__ void zl_bwd(f2 (&p)[L::E], f2 (&c)[L::E], const ZlTab
     if constexpr (T::DL) {
 #pragma unroll
         for (int e = 0; e < E; e++) p[e] = pk_fma(splat(-t.td), ppd[e], p[e]);
-        zl_stage<L, UP>(p, -t.tu);
+        zl_stage<L, UP, true>(p, t.tu);
     } else if constexpr (T::UL) {
 #pragma unroll
         for (int e = 0; e < E; e++) p[e] = pk_fma(splat(-t.tu), ppu[e], p[e]);
-        zl_stage<L, DN>(p, -t.td);
+        zl_stage<L, DN, true>(p, t.td);
     } else {
-        zl_stage<L, DN>(p, -t.td);
-        zl_stage<L, UP>(p, -t.tu);
+        zl_stage<L, DN, true>(p, t.td);
+        zl_stage<L, UP, true>(p, t.tu);
     }
-    zl_stage<L, DN>(c, -t.td);
-    zl_stage<L, UP>(c, -t.tu);
+    zl_stage<L, DN, true>(c, t.td);
+    zl_stage<L, UP, true>(c, t.tu);
     // the |11> sum before conj(d) (both matrices carry 1 / d_0 here: cpf_zyz_math.h chain_cp)
     {
         f2 cc = {0.f, 0.f};
