@@ -777,7 +777,11 @@ int launch_jit(cpf_plan* plan, const cpf::KArgs& a, const JitCandidate& c, const
 // angles.  Same box, ms by cut (config 2's shape, 12 blocks, unless named; profiles/r05_cfg2_levers_ab.txt):
 //   one sample per CU      256 samples: 4.12 / 3.93 / 3.80 at 4 / 5 / 6; 100 samples of 14 blocks 4.39 / 4.12 / 4.11 at 5 / 6 / 7
 //                                                                                                        -> K / 2
-//   more, all resident     1024: 4.31 / 4.23 at 3 / 4 (before wave A's tracking moved behind its gradient half: 4.48 / 4.37 / 4.46 /
+//   two samples per CU     (round 6's kernel: one wave on every SIMD, nothing shares it) config 2's shape at 512 samples 3.88 / 3.94 / 4.09 at
+//                          3 / 4 / 5; config 3's shape (16 blocks) at 512: 4.94 / 4.73 / 4.31 / 4.35 at 2 / 3 / 4 / 5 (768 samples of
+//                          config 2's shape: 3.93 / 3.95 at 3 / 4)                                          -> 0.25 K, rounded
+//   more, all resident     (round 6: 1024 samples 4.06 / 4.04 / 4.00 at 2 / 3 / 4; config 3's shape at 1024: 4.48 / 4.44 / 4.48 at 4 / 5 / 6)
+//                          round 5 - 1024: 4.31 / 4.23 at 3 / 4 (before wave A's tracking moved behind its gradient half: 4.48 / 4.37 / 4.46 /
 //                          4.57 at 2 / 3 / 4 / 5); config 3's shape (16 blocks) 512: 4.66 / 4.71 at 5 / 6     -> 0.33 K, rounded
 //   in rounds              2048: 10.72 / 10.54 at 4 / 5; (before the two-lane owner layout) 4096: 22.70 / 21.75 at 4 / 5, config 3's
 //                          shape 4096: 23.2 / 22.6 at 6 / 7                                              -> 0.43 K
@@ -798,7 +802,7 @@ int zyz3_pairs(const cpf_plan* plan, int64_t S) {
 int zyz3_cut(const cpf_plan* plan, int64_t S) {
     const int K = plan->K;
     const int64_t per_cu = zyz3_per_cu(plan, S);
-    int m = per_cu <= 1 ? K / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (zyz3_all_resident(plan, S) ? (33 * K + 50) / 100 : (43 * K + 50) / 100));
+    int m = per_cu <= 1 ? K / 2 : (zyz3_pairs(plan, S) == 2 ? K / 2 : (per_cu == 2 ? (25 * K + 50) / 100 : (zyz3_all_resident(plan, S) ? (33 * K + 50) / 100 : (43 * K + 50) / 100)));
     { const TuneVal e = tuning("CPF_ZYZ3_M"); if (e) m = atoi(e.s.c_str()); }
     return std::max(1, std::min(K - 1, m));
 }
@@ -1352,12 +1356,12 @@ int32_t cpf_jit_precompile(const cpf_problem* pb, int64_t num_samples, char* buf
     // 3 qubits: the two-ended ZYZ-form kernel (cpf_zyz3.h), the default at every number of samples - then nothing else
     // is built for the shape: the gate-by-gate kernels that read the block count from the plan are part of the library
     if (zyz3_serves(&pl, cpf::MODE_OPTIMIZE, loss_kind) && zyz3_selected()) {
-        // every launch regime's cut (zyz3_cut: K / 2 at one sample per CU, 0.33 K while all workgroups are resident, 0.43 K in rounds),
+        // every launch regime's cut (zyz3_cut: K / 2 at one sample per CU, 0.25 K at two, 0.33 K while all workgroups are resident, 0.43 K in rounds),
         // whatever `num_samples` says: which regime a launch falls into depends on the device's CU count and LDS size, and a
         // cache built for one sample count must not make another one compile on the launch path.  CPF_ZYZ3_M, when
         // set, names the one cut to build.
         const int rot = dense_rot_code(&pl), pairs = zyz3_pairs(&pl, num_samples), K = pl.K;
-        std::vector<int> cuts = {K / 2, (33 * K + 50) / 100, (43 * K + 50) / 100};
+        std::vector<int> cuts = {K / 2, (25 * K + 50) / 100, (33 * K + 50) / 100, (43 * K + 50) / 100};
         if (tuning("CPF_ZYZ3_M")) cuts = {zyz3_cut(&pl, num_samples)};
         std::set<int> seen;
         for (int m : cuts) {

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     CHECK(cpf_jit_precompile(&pb, 64, buf, sizeof(buf)) < 0 && strstr(cpf_last_error(), "CPF_JIT_FORBID_COMPILE"));
     unsetenv("CPF_JIT_FORBID_COMPILE");
     // (a 3-qubit shape: the two-ended ZYZ-form kernel, cpf_zyz3.h, and nothing else.  Since round 6 the precompile step builds
-    // every launch regime's cut of a shape - here 9 blocks: cuts 4 and 3 - unless CPF_ZYZ3_M names one; one cut keeps this driver quick)
+    // every launch regime's cut of a shape - here 9 blocks: cuts 4, 2 and 3 - unless CPF_ZYZ3_M names one; one cut keeps this driver quick)
     CHECK(cpf_set_tuning("CPF_ZYZ3_M", "4") == 0);
     int n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));
     CHECK(n == 1 && strstr(buf, "[built]") && strstr(buf, "zyz3/jit("));
@@ -74,10 +74,10 @@ int main(int argc, char** argv) {
         CHECK(cpf_set_tuning("CPF_NOT_A_SWITCH", "1") < 0 && cpf_set_tuning("CPF_SPLIT", "0") == 0 && cpf_set_tuning("CPF_SPLIT", nullptr) == 0);
     }
     CHECK(cpf_set_tuning("CPF_ZYZ3_M", nullptr) == 0);
-    n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));           // both cuts now: 4 from the cache, 3 built
-    CHECK(n == 2 && strstr(buf, "cut=4 [cached]") && strstr(buf, "cut=3 [built]"));
+    n = cpf_jit_precompile(&pb, 64, buf, sizeof(buf));           // every cut now: 4 from the cache, 2 and 3 built
+    CHECK(n == 3 && strstr(buf, "cut=4 [cached]") && strstr(buf, "cut=2 [built]") && strstr(buf, "cut=3 [built]"));
     const int compiles_so_far = cpf_jit_compiles();
-    CHECK(compiles_so_far >= 4);
+    CHECK(compiles_so_far >= 5);
     // shapes served by ahead-of-time kernels need nothing: config 2 (3 qubits, chain) -> the JIT candidates exist but are never
     // reached at run time; config 5 (6 qubits on a ring) -> the dense-block instance is built ahead of time
     std::vector<int32_t> ring6; for (int b = 0; b < 60; b++) { ring6.push_back(b % 6); ring6.push_back((b % 6 + 1) % 6); }

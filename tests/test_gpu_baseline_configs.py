@@ -79,8 +79,8 @@ def test_config3_toffoli_all_to_all_at_size():
     for S, first in ((512, 1024), (4096, 0)):          # rank 2's block of the 8-GPU run; all samples on one GPU
         init = eng.initial_angles(wl.seed, 4096, first, S)
         out = _np(eng.optimize(init))
-        # 512 samples = two per CU, all resident: 5 of the 16 blocks in wave A; 4096 = four rounds of four per CU: 7
-        assert eng.last_variant() == f'zyz3/aot waves=2 K cut={5 if S == 512 else 7}', eng.last_variant()
+        # 512 samples = two per CU (one wave on every SIMD): 4 of the 16 blocks in wave A; 4096 = four rounds of four per CU: 7
+        assert eng.last_variant() == f'zyz3/aot waves=2 K cut={4 if S == 512 else 7}', eng.last_variant()
         _check_size_independent_properties(eng, init, out, S)
         ok = out['passed']
         assert ok.mean() > 0.5 and out['cz'][ok].min() <= 8          # Toffoli needs 6 CZ all-to-all; most starts converge

@@ -272,8 +272,9 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     lines = json.loads(r.stdout.strip().splitlines()[-1])
     # a 3-qubit shape whose samples are all resident at once: the two-ended ZYZ-form kernel (cpf_zyz3.h), specialised on the block
     # count and the cut, and nothing else (the gate-by-gate kernels that read the block count from the plan are in the library)
-    assert len(lines) == 1 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
-    assert lines[0].startswith('zyz3/jit(hipcc) waves=2 K cut=2 [built] cpf::zyz3_body<'), lines
+    # (5 blocks: the launch regimes' cuts K / 2, 0.33 K and 0.43 K are all 2, the two-samples-per-CU regime's 0.25 K is 1)
+    assert len(lines) == 2 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
+    assert lines[0].startswith('zyz3/jit(hipcc) waves=2 K cut=2 [built] cpf::zyz3_body<') and lines[1].startswith('zyz3/jit(hipcc) waves=2 K cut=1 [built] '), lines
     assert (os.stat(tmp_path / 'cache').st_mode & 0o077) == 0          # private directory
     r = run({'CPF_JIT_FORBID_COMPILE': '1'})                           # now served from the cache
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
@@ -300,18 +301,18 @@ def test_block_count_specialised_kernels_per_regime(tmp_path):
         lines = json.loads(r.stdout.strip().splitlines()[-1])
         return [re.sub(r'jit\(\w+\)', 'jit(hipcc)', x.replace('[built]', '[cached]')) for x in lines]
     # every 3-qubit shape runs on the two-ended ZYZ-form kernel; block count, cut (= blocks of wave A) and samples per workgroup are
-    # template arguments: one sample per CU -> K / 2; more, all resident -> 0.33 K rounded; launches that run in rounds -> 0.43 K
-    # (cpflow_amd.hip zyz3_cut).  Round 6: the precompile step builds ALL THREE cuts of a shape whatever the sample count says (which
+    # template arguments: one sample per CU -> K / 2; two -> 0.25 K rounded; more, all resident -> 0.33 K; launches that run in rounds -> 0.43 K
+    # (cpflow_amd.hip zyz3_cut).  Round 6: the precompile step builds ALL FOUR cuts of a shape whatever the sample count says (which
     # regime a launch falls into depends on the device), so a cache built for one sample count serves every launch of the shape.
     for S in (100, 700, 8192):
         got = kernels(14, S)
-        assert [x.split(' [cached] ')[0] for x in got] == ['zyz3/jit(hipcc) waves=2 K cut=7', 'zyz3/jit(hipcc) waves=2 K cut=5', 'zyz3/jit(hipcc) waves=2 K cut=6'], got
+        assert [x.split(' [cached] ')[0] for x in got] == ['zyz3/jit(hipcc) waves=2 K cut=7', 'zyz3/jit(hipcc) waves=2 K cut=4', 'zyz3/jit(hipcc) waves=2 K cut=5', 'zyz3/jit(hipcc) waves=2 K cut=6'], got
         assert got[0].endswith('cpf::zyz3_body<8451, 14, 7, 1, 0, 1, 1, 2>'), got
-    assert kernels(12, 8192) == []                                                          # config 2's shape: all three cuts built into the library
-    assert [x.split(' [cached] ')[0] for x in kernels(24, 100)] == [f'zyz3/jit(hipcc) waves=2 K cut={m}' for m in (12, 8, 10)]      # 54 KB of LDS per sample
+    assert kernels(12, 8192) == []                                                          # config 2's shape: all four cuts built into the library
+    assert [x.split(' [cached] ')[0] for x in kernels(24, 100)] == [f'zyz3/jit(hipcc) waves=2 K cut={m}' for m in (12, 6, 8, 10)]      # 54 KB of LDS per sample
     # the cuts a launch would ask for are among them (tests/zyz3_shape.py restates the host's rule)
     import zyz3_shape
-    for K, S in ((14, 100), (14, 512), (14, 8192), (20, 100), (24, 1000)):
+    for K, S in ((14, 100), (14, 512), (14, 700), (14, 8192), (20, 100), (20, 400), (24, 1000)):
         assert any(f' cut={zyz3_shape.cut(K, S)} ' in x for x in kernels(K, 1000)), (K, S)
     # a switch that selects another 3-qubit family is honoured by the precompile step as it is by a launch
     assert not any(x.startswith('zyz3/') for x in kernels(14, 100, {'CPF_ZYZ3': '0'})) and kernels(14, 100, {'CPF_ZYZ3': '0'})[0].startswith('split/')

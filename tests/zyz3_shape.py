@@ -21,6 +21,8 @@ def cut(K, S):
         m = K // 2
     elif pairs(K, S) == 2:
         m = K // 2
+    elif per_cu == 2:
+        m = (25 * K + 50) // 100
     elif per_cu <= fit:
         m = (33 * K + 50) // 100
     else:
