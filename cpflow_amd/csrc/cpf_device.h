@@ -636,10 +636,23 @@ __device__ __forceinline__ float penalty_lds(const float* tab, int pen_kind, flo
         slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
         return fabsf(ang);
     }
+    // The piece without compares: a packed (x - lo) * 2^40 clamped to [0, 1] is exactly 1 above a break point and 0 at or below it
+    // (x and the eight interior break points are float32 numbers of [0, 2 pi]: where they differ they differ by more than 2^-30; the
+    // product by a power of two is exact).  Four packed FMAs and four adds where eight v_cmp / v_cndmask pairs each waited two
+    // states for their mask (~45 instructions with their s_nop in the listings of rounds 5 and 6); the same piece, the same two roundings.
     const float x = floor_mod_2pi(ang);
     const float4 l0 = *reinterpret_cast<const float4*>(tab + PEN_LO);
     const float4 l1 = *reinterpret_cast<const float4*>(tab + PEN_LO + 4);
-    const int idx = (x > l0.x) + (x > l0.y) + (x > l0.z) + (x > l0.w) + (x > l1.x) + (x > l1.y) + (x > l1.z) + (x > l1.w);
+    constexpr float BIG = 1099511627776.f;                   // 2^40
+    const f2 xb = {x * BIG, x * BIG};
+    f2 c0, c1, c2, c3;
+    asm("v_pk_fma_f32 %0, %3, %4, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+        "v_pk_fma_f32 %1, %3, %5, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+        "v_pk_fma_f32 %2, %3, %6, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp"
+        : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(f2{BIG, BIG}), "v"(f2{l0.x, l0.y}), "v"(f2{l0.z, l0.w}), "v"(f2{l1.x, l1.y}), "v"(xb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c3) : "v"(f2{BIG, BIG}), "v"(f2{l1.z, l1.w}), "v"(xb));
+    const f2 cs01 = (c0 + c1) + (c2 + c3);
+    const int idx = (int)(cs01.x + cs01.y);
     const float2 si = *reinterpret_cast<const float2*>(tab + PEN_SI + 2 * idx);
     slope = si.x;
     return __fadd_rn(__fmul_rn(si.x, x), si.y);

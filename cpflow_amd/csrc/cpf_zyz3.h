@@ -276,33 +276,9 @@ __device__ __forceinline__ void z3_products(f2 v, f2 pre, f2 pim, f2& px, f2& py
             "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
             : "=&v"(px), "=&v"(py) : "v"(v), "v"(pre), "v"(pim));
 }
-// The penalty of one CP angle and its slope (penalty.py:44-71) as cpf_device.h penalty_lds evaluates them - the same piece, the same
-// two roundings - with the piece found without compares: the index is the number of break points below x, and a packed
-// (x - lo) * 2^40 clamped to [0, 1] is exactly 1 above a break point and 0 at or below it (x and the break points are float32
-// numbers of [0, 2 pi]: where they differ they differ by more than 2^-30; the product by a power of two is exact).  Four packed
-// FMAs and four adds where eight v_cmp / v_cndmask pairs each waited two states for their mask (round 5's listing: ~25 instructions).
-__device__ __forceinline__ float z3_penalty(const float* tab, int pen_kind, float ang, float& slope) {
-    if (pen_kind == 1) {                                      // penalty.py:74-76
-        slope = (ang > 0.f) ? 1.f : ((ang < 0.f) ? -1.f : 0.f);
-        return fabsf(ang);
-    }
-    const float x = floor_mod_2pi(ang);
-    const float4 l0 = *reinterpret_cast<const float4*>(tab + PEN_LO);
-    const float4 l1 = *reinterpret_cast<const float4*>(tab + PEN_LO + 4);
-    constexpr float BIG = 1099511627776.f;                   // 2^40
-    const f2 xb = splat(x * BIG);
-    f2 c0, c1, c2, c3;
-    asm("v_pk_fma_f32 %0, %3, %4, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-        "v_pk_fma_f32 %1, %3, %5, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-        "v_pk_fma_f32 %2, %3, %6, %7 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp"
-        : "=&v"(c0), "=&v"(c1), "=&v"(c2) : "v"(f2{BIG, BIG}), "v"(f2{l0.x, l0.y}), "v"(f2{l0.z, l0.w}), "v"(f2{l1.x, l1.y}), "v"(xb));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c3) : "v"(f2{BIG, BIG}), "v"(f2{l1.z, l1.w}), "v"(xb));
-    const f2 cs01 = (c0 + c1) + (c2 + c3);
-    const int idx = (int)(cs01.x + cs01.y);
-    const float2 si = *reinterpret_cast<const float2*>(tab + PEN_SI + 2 * idx);
-    slope = si.x;
-    return __fadd_rn(__fmul_rn(si.x, x), si.y);
-}
+// The penalty of one CP angle and its slope (penalty.py:44-71): cpf_device.h penalty_lds (since round 6 the compare-free form this
+// kernel introduced serves every kernel).
+__device__ __forceinline__ float z3_penalty(const float* tab, int pen_kind, float ang, float& slope) { return penalty_lds(tab, pen_kind, ang, slope); }
 // the value held by the partner lane on row qubit Q (lane bits 0, 1, 3); every lane takes part
 template <int Q>
 __device__ __forceinline__ float z3_partner(float v) {
