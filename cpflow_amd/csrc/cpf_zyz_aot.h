@@ -15,7 +15,11 @@ bool cpf_zyz_has_aot(int nq, int lw, int rot, const std::vector<int>& ud);
 
 // The same for the ZYZ form on the gate-by-gate layout (cpf_zyzl.h; one wave per sample): config 4's chain_layer(4) in the
 // plan's relabelling (0, 1, 2, 3) -> (0, 2, 3, 1).  grid / block: workgroups and threads per workgroup (64 per sample).
-// nslot: items (sides + qubits) per lane, (2 K + n + 63) / 64; the instance holds one (K <= 30 at 4 qubits).
+// nslot: items (sides + qubits) per lane, (2 K + n + 63) / 64; the instances hold one (K <= 30 at 4 qubits) - plus 16 x the number
+// of layers whose blocks' input states stay in registers (cpf_zyzl.h SAVE): 0 and CPF_ZYZL_AOT_SAVE are built.
+#ifndef CPF_ZYZL_AOT_SAVE
+#define CPF_ZYZL_AOT_SAVE 2      // what 256 registers per lane hold beside the kernel's own ~190 (3: 123 spills, 5: 223)
+#endif
 int cpf_zyzl_launch_aot(int nq, int rot, int nslot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
                         hipStream_t stream, hipError_t* err);
 bool cpf_zyzl_has_aot(int nq, int rot, int nslot, const std::vector<int>& ud);

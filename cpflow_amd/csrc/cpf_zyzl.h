@@ -255,6 +255,55 @@ __device__ __forceinline__ void zl_bwd(f2 (&p)[L::E], f2 (&c)[L::E], const ZlTab
     for (int e = 0; e < E; e++) { p[e] = zl_mul_conj(t.ph[T::idx(e)], t.pn[T::idx(e)], p[e]); c[e] = zl_mul_conj(t.ph[T::idx(e)], t.pn[T::idx(e)], c[e]); }
 }
 
+// The same for a block whose input state the forward sweep kept (zyzl_body, SAVE): p = the state right after the block (kept as the
+// next block's input, or the sweep's final state), q = the state in front of it.  Nothing is un-applied from psi - its two stages and
+// its conj(d), 16 of the block's ~110 instructions - and the |11> sum is taken AFTER conj(d), from the cotangent in front of the
+// block and q: both carry the block's real scale d_0 there instead of 1 / d_0, so the sum is d_0^2 times the one zl_bwd forms and
+// chain_cp gets d_0 = 1 for such a block.  (The recomputed state equals q up to rounding: the unnormalised stages' (1 + t^2)
+// factors and |d|^2 cancel.)
+template <class L, int UP, int DN>
+__device__ __forceinline__ void zl_bwd_saved(const f2 (&p)[L::E], const f2 (&q)[L::E], f2 (&c)[L::E], const ZlTab<L, UP, DN>& t, const ZlLane<L>& ln, float (&d8)[8]) {
+    using T = ZlTab<L, UP, DN>;
+    constexpr int E = L::E;
+    f2 z[T::NPH];
+#pragma unroll
+    for (int k = 0; k < T::NPH; k++) z[k] = f2{0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < E; e++) z[T::idx(e)] = pk_fma(c[e], swp(p[e]), z[T::idx(e)]);
+    float tz[T::NPH];
+#pragma unroll
+    for (int k = 0; k < T::NPH; k++) tz[k] = z[k].x - z[k].y;
+    {
+        float u0 = 0.f, u1 = 0.f, v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int iu = 0; iu < T::NU; iu++)
+#pragma unroll
+            for (int id = 0; id < T::ND; id++) {
+                const float v = tz[iu * T::ND + id];
+                if (iu == 0) u0 += v; else u1 += v;
+                if (id == 0) v0 += v; else v1 += v;
+            }
+        if constexpr (T::UL) d8[2] = -ln.sg[UP] * u0; else d8[2] = u0 - u1;
+        if constexpr (T::DL) d8[5] = -ln.sg[DN] * v0; else d8[5] = v0 - v1;
+    }
+    f2 ppu[E], ppd[E];
+    zl_xy_sums<L, UP>(p, c, ln, d8[0], d8[1], ppu);
+    zl_xy_sums<L, DN>(p, c, ln, d8[3], d8[4], ppd);
+    zl_stage<L, DN, true>(c, t.td);
+    zl_stage<L, UP, true>(c, t.tu);
+#pragma unroll
+    for (int e = 0; e < E; e++) c[e] = zl_mul_conj(t.ph[T::idx(e)], t.pn[T::idx(e)], c[e]);
+    {
+        f2 cc = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; e++) if (T::both_set(e)) cc = pk_fma(c[e], swp(q[e]), cc);
+        float s11 = cc.x - cc.y;
+        if constexpr (T::UL) s11 = ln.lb[UP] ? s11 : 0.f;
+        if constexpr (T::DL) s11 = ln.lb[DN] ? s11 : 0.f;
+        d8[6] = s11; d8[7] = 0.f;
+    }
+}
+
 // x[e] = base * prod over the register qubits of f_q[bit of e] (register bit rb holds qubit NLR + rb)
 template <class L, class F>
 __device__ __forceinline__ void zl_product(f2 (&x)[L::E], f2 base, const F& fac) {
@@ -310,14 +359,21 @@ __device__ __forceinline__ void zl_wave_sum3(float& re, float& im, float& pen, b
 // surface matrices, the reduced sums).
 // LW: log2 of the waves per sample - 0 (one wave; up to four samples per workgroup) or 2 (four waves: the columns are split over
 // the waves, for launches with at most one sample per CU; the items spread over all 256 lanes).
-template <int NQ, int LW, int ROT, int NSLOT, int... UD>
+// NSLOT_SAVE = NSLOT + 16 SAVE.  SAVE > 0 (one wave per sample, 4 amplitudes per lane; the host guarantees K = a whole number of
+// layers >= SAVE): the input states of the blocks of the last SAVE layers stay in registers from the forward sweep (8 registers per
+// block: a launch of this kernel has at most two waves per SIMD = 256 registers per lane), the backward sweep's first SAVE layers take
+// psi from there instead of un-applying the blocks from it (zl_bwd_saved) - config 4: 15 of 24 blocks, 16 of ~110 instructions each.
+template <int NQ, int LW, int ROT, int NSLOT_SAVE, int... UD>
 __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
+    constexpr int NSLOT = NSLOT_SAVE & 15, SAVE = NSLOT_SAVE >> 4;
     using L = Lay<NQ, LW>;
     constexpr int WPS = L::WPS, THREADS = L::THREADS;
     using PL = PairList<UD...>;
     constexpr int LL = sizeof...(UD) / 2;
     static_assert(LL > 0 && ROT != 0, "the ZYZ-form kernel is specialised on the layer and the rotation string");
     constexpr int E = L::E, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
+    constexpr int NSAVE = SAVE * LL;                       // blocks K - NSAVE .. K - 1
+    static_assert(SAVE == 0 || (WPS == 1 && E <= 4 && NSAVE * E * 2 <= 160), "kept states: one wave per sample, at most 160 registers of them");
     constexpr int NR = ROT & 15, ENT = (ROT >> 16) & 3, NBP = 2 * NR + (ENT == 0 ? 1 : 0);
     static_assert(NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     const KArgs& a = za.k;
@@ -349,7 +405,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     const char* tbase = reinterpret_cast<const char*>(a.target);
     // 4 qubits (4 amplitudes per lane): the lane's target elements stay in registers for the whole run (8 registers of a kernel that may
     // use 256: two waves per SIMD at most) instead of four global loads in the loss and four more before the backward sweep of every step
-    constexpr bool TREG = E <= 4;
+    constexpr bool TREG = E <= 4 && (NSLOT_SAVE >> 4) == 0;      // (the instance that keeps states has no registers to spare: it re-reads)
     float2 treg[TREG ? E : 1];
     if constexpr (TREG) {
 #pragma unroll
@@ -445,6 +501,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     };
 
     f2 psi[E], cot[E];
+    f2 kept[NSAVE > 0 ? NSAVE : 1][E];
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
@@ -585,8 +642,15 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 gate_fence<L>();
                 b++;
             };
-            for (int full = K / LL; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
-            static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); }, typename make_iseq<LL>::type{});
+            for (int full = K / LL - SAVE; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
+            if constexpr (SAVE > 0) {
+                static_for([&](auto ii) __attribute__((always_inline)) {
+                    constexpr int I = decltype(ii)::value;
+#pragma unroll
+                    for (int e = 0; e < E; e++) kept[I][e] = psi[e];          // the state in front of block K - NSAVE + I
+                    fwd_step(ic<I % LL>{});
+                }, typename make_iseq<NSAVE>::type{});
+            } else static_for([&](auto jj) __attribute__((always_inline)) { if (b < K) fwd_step(jj); }, typename make_iseq<LL>::type{});
         }
 
         CPF_MARK(loss);
@@ -702,12 +766,33 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 gate_fence<L>();
                 b--;
             };
-            const int tail = K % LL;                   // blocks beyond the last whole layer come first
-            static_for([&](auto jj) __attribute__((always_inline)) {
-                constexpr int J = LL - 1 - decltype(jj)::value;
-                if (J < tail) bwd_step(jj);
-            }, typename make_iseq<LL>::type{});
-            for (int full = K / LL; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
+            if constexpr (SAVE > 0) {
+                static_for([&](auto ii) __attribute__((always_inline)) {
+                    constexpr int I = NSAVE - 1 - decltype(ii)::value, J = I % LL, JN = (J + LL - 1) % LL;
+                    const ZlRaw cur = nxt;
+                    zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, btn, ln);
+                    btn -= ZYZL_TAB_FLOATS;
+                    __builtin_amdgcn_sched_barrier(0);
+                    ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
+                    zl_use(t, cur, ln);
+                    float d8[8];
+                    if constexpr (I == NSAVE - 1) zl_bwd_saved<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, kept[I], cot, t, ln, d8);
+                    else zl_bwd_saved<L, PL::v[2 * J], PL::v[2 * J + 1]>(kept[I + 1 < NSAVE ? I + 1 : I], kept[I], cot, t, ln, d8);
+                    reduce8_rows<true>(d8, sums_b, lane, dst_lane);
+                    sums_b -= 32;
+                    gate_fence<L>();
+                    b--;
+                }, typename make_iseq<NSAVE>::type{});
+#pragma unroll
+                for (int e = 0; e < E; e++) psi[e] = kept[0][e];             // the state in front of block K - NSAVE: the other layers un-apply from here
+            } else {
+                const int tail = K % LL;                   // blocks beyond the last whole layer come first
+                static_for([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = LL - 1 - decltype(jj)::value;
+                    if (J < tail) bwd_step(jj);
+                }, typename make_iseq<LL>::type{});
+            }
+            for (int full = K / LL - SAVE; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
         }
         CPF_MARK(gsurf);
         {   // generator sums of every qubit at the surface state
@@ -771,7 +856,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                         const int wp = st[0], q = st[1];
                         pzq[sd2] = wp < 0 ? slab_sum(lds.gsurf, NBATCH * 32, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, K * 32, wp >> 1, 3 * (wp & 1) + 2);
                     }
-                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], t.cacb, t.d0);
+                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], t.cacb, (NSAVE > 0 && b >= K - NSAVE) ? 1.f : t.d0);
                 }
             } else if (t.kind == 1) {
                 const int q = i - 2 * K;
@@ -825,9 +910,11 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     }
 }
 
-template <int NQ, int LW, int ROT, int NSLOT, int... UD>
-__global__ __launch_bounds__(256, 1) void k_cp_zyzl(const ZyzlArgs za) {
-    zyzl_body<NQ, LW, ROT, NSLOT, UD...>(za);
+// (the instance that keeps states runs two waves per SIMD like the others: its registers, kept states included, must fit 256 per lane -
+// without the second bound the compiler parks the kept states in accumulation registers, 394 in all, and halves the residency)
+template <int NQ, int LW, int ROT, int NSLOT_SAVE, int... UD>
+__global__ __launch_bounds__(256, (NSLOT_SAVE >> 4) != 0 ? 2 : 1) void k_cp_zyzl(const ZyzlArgs za) {
+    zyzl_body<NQ, LW, ROT, NSLOT_SAVE, UD...>(za);
 }
 
 }  // namespace cpf

@@ -626,10 +626,19 @@ bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
     // every row qubit on lanes, 17.4 against 16.2: stays).  3 qubits: on request (the A/B of DESIGN.md section 4)
     return e ? e[0] != '0' : (lw == 0 ? plan->NQ >= 4 : (lw == 2 && plan->NQ == 5));
 }
+// Layers whose blocks' input states the forward sweep keeps in registers (cpf_zyzl.h SAVE: the backward sweep does not un-apply those
+// blocks from psi).  Shipped instances only - config 4's shape with at least five whole layers (15 kept states = 120 registers) - so
+// that no run-time built shape gains a variant; CPF_ZYZL_SAVE=0 selects the instance without (parity tests run both).
+int zyzl_saved_layers(const cpf_plan* plan, int lw, int rot, int nslot) {
+    const int LL = (int)plan->layer_ud.size() / 2;
+    if (lw != 0 || plan->NQ != 4 || nslot != 1 || LL < 1 || plan->K % LL != 0 || plan->K / LL < CPF_ZYZL_AOT_SAVE) return 0;
+    { const TuneVal e = tuning("CPF_ZYZL_SAVE"); if (e && e[0] == '0') return 0; }
+    return cpf_zyzl_has_aot(plan->NQ, rot, nslot + 16 * CPF_ZYZL_AOT_SAVE, plan->layer_ud) ? CPF_ZYZL_AOT_SAVE : 0;
+}
 bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
     const int nq = plan->NQ, rot = dense_rot_code(plan), which = labelling_for(plan, a_in.mode, lw);
-    const int nslot = zyzl_slots(plan, lw);
+    const int nslot1 = zyzl_slots(plan, lw), save = zyzl_saved_layers(plan, lw, rot, nslot1), nslot = nslot1 + 16 * save;
     const bool have_aot = lw == 0 && cpf_zyzl_has_aot(nq, rot, nslot, plan->layer_ud);
     const cpf_jit::Kernel* jk = nullptr;
     if (!have_aot) {
@@ -654,7 +663,7 @@ bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStre
     const std::string tail = " waves=" + std::to_string(1 << lw) + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
     if (have_aot) {
         cpf_zyzl_launch_aot(nq, rot, nslot, plan->layer_ud, za, grid, block, lds, stream, &e);
-        plan->variant = "zyzl/aot" + tail;
+        plan->variant = "zyzl/aot" + tail + (save ? " kept=" + std::to_string(save) : "");
     } else {
         if (!module_lds_opt_in(jk->fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the ZYZ-form kernel"; return false; }
         cpf::ZyzlArgs args = za;
@@ -1052,7 +1061,7 @@ int32_t cpf_set_tuning(const char* name, const char* value) {
     // side.  Timing experiments and instrumented builds (phase stamps, extra -D flags handed to the run-time compiler, residency and
     // forced-generic switches) exist in a library built with -DCPF_DIAGNOSTICS only (tools/gpu.py, cpflow_amd.build.build_variant).
     static const char* const known[] = {"CPF_SPLIT", "CPF_PSTORE", "CPF_MSTORE", "CPF_KSPEC", "CPF_PAIRS", "CPF_LONE", "CPF_PRIO", "CPF_LW", "CPF_GROUP",
-                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_RELABEL",
+                                        "CPF_DENSE", "CPF_DENSE_LW", "CPF_DENSE_SPECIALISED", "CPF_DENSE_FOLD", "CPF_ZYZ", "CPF_ZYZL", "CPF_ZYZL_SAVE", "CPF_RELABEL",
                                         "CPF_JIT", "CPF_JIT_K", "CPF_ZYZ3", "CPF_ZYZ3_M", "CPF_ZYZ3_PAIRS",
 #ifdef CPF_DIAGNOSTICS
                                         "CPF_FORCE_GENERIC", "CPF_NO_AOT3", "CPF_ZYZ3_RES", "CPF_ZYZ3_STAMPS", "CPF_ZYZ3_DEFS",

@@ -156,7 +156,7 @@ int32_t cpf_jit_compiles(void);
 /* Test hook, not part of what a cpflow binding needs: forces a kernel FAMILY / layout for parity tests that put two families of one
  * shape side by side (value NULL restores the default).  The release library knows exactly these names: CPF_SPLIT, CPF_PSTORE,
  * CPF_MSTORE, CPF_KSPEC, CPF_PAIRS, CPF_LONE, CPF_PRIO, CPF_LW, CPF_GROUP, CPF_DENSE, CPF_DENSE_LW, CPF_DENSE_SPECIALISED,
- * CPF_DENSE_FOLD, CPF_ZYZ, CPF_ZYZL, CPF_RELABEL, CPF_JIT, CPF_JIT_K, CPF_ZYZ3, CPF_ZYZ3_M, CPF_ZYZ3_PAIRS (values: tools/README.md).
+ * CPF_DENSE_FOLD, CPF_ZYZ, CPF_ZYZL, CPF_ZYZL_SAVE, CPF_RELABEL, CPF_JIT, CPF_JIT_K, CPF_ZYZ3, CPF_ZYZ3_M, CPF_ZYZ3_PAIRS (values: tools/README.md).
  * Timing experiments and instrumented kernels (phase stamps, extra compiler flags for run-time builds, forced generic kernel, ...)
  * exist only in a library built with -DCPF_DIAGNOSTICS (tools/gpu.py).  Process-wide and thread-safe;
  * a plan reads the switches when it is created and at every launch, and caches what it derived from them (per-block tables),

@@ -873,7 +873,10 @@ def test_zyz_form_gradient_at_degenerate_angles(tune):
 ZYZL_CASES = [
     # (layer, K, rot, entangler, ahead-of-time instance / run-time build)
     ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', 'aot'),                      # config 4's layer (relabelled by the plan): lane + register, register + register
-    ([[0, 1], [1, 2], [2, 3]], 24, 'xyz', 'cp', 'aot'),                      # config 4's block count
+    ([[0, 1], [1, 2], [2, 3]], 24, 'xyz', 'cp', 'aot'),                      # config 4's block count: the last 5 of its 8 layers keep their input states
+    ([[0, 1], [1, 2], [2, 3]], 15, 'xyz', 'cp', 'aot'),                      # exactly 5 layers: every block's input state kept, nothing un-applied from psi
+    ([[0, 1], [1, 2], [2, 3]], 18, 'xyz', 'cp', 'aot'),                      # one layer un-applied behind five kept ones
+    ([[0, 1], [1, 2], [2, 3]], 12, 'xyz', 'cp', 'aot'),                      # four layers: below the kept-states instance's five
     ([[0, 1], [0, 2], [0, 3]], 8, 'xyz', 'cp', 'jit'),                       # 4-qubit star (tutorial/results/toff4_star)
     ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', 'jit'),                # twisted placements, two letters
     ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', 'jit'),              # 5 qubits: 16 amplitudes per lane, one lane qubit
@@ -928,6 +931,18 @@ def test_zyz_form_on_the_gate_by_gate_layout_matches_oracle(layer, K, rot, ent, 
     frozen[1::2, ::5] = 1
     outf = {k: v.cpu().numpy() for k, v in eng.optimize(init, frozen=frozen).items()}
     assert (outf['params'][:, 1][frozen == 1] == init[frozen == 1]).all()
+    # config 4's shape with at least five whole layers runs the instance that keeps the input states of the last five layers' blocks
+    # in registers (cpf_zyzl.h SAVE); the instance without must agree with it to rounding on the whole history
+    kept = how == 'aot' and relabel == '1' and K % len(layer) == 0 and K // len(layer) >= 2
+    assert (' kept=' in eng.last_variant()) == kept, eng.last_variant()
+    if kept:
+        tune.set('CPF_ZYZL_SAVE', '0')
+        eng1 = _engine(layer, K, target, rot, **kw)
+        out1 = {k: v.cpu().numpy() for k, v in eng1.optimize(init, keep_history=True).items()}
+        assert eng1.last_variant().startswith('zyzl/aot waves=1') and ' kept=' not in eng1.last_variant(), eng1.last_variant()
+        assert np.abs(out1['history_regloss'] - out['history_regloss'])[:4].max() < 1e-5
+        assert np.abs(out1['history_params'] - out['history_params'])[:4, :3].max() < 3e-5
+        tune.unset('CPF_ZYZL_SAVE')
     tune.set('CPF_ZYZL', '0')                   # the gate-by-gate kernel on the same inputs
     eng0 = _engine(layer, K, target, rot, **kw)
     out0 = {k: v.cpu().numpy() for k, v in eng0.optimize(init, frozen=frozen).items()}

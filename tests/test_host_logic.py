@@ -38,7 +38,7 @@ def test_release_library_knows_the_family_switches_only():
     doc = header[header.index('The release library knows exactly these names:'):header.index('(values: tools/README.md)')]
     release = sorted(set(re.findall(r'\bCPF_[A-Z0-9_]+\b', doc)))
     assert release == sorted(['CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_GROUP', 'CPF_DENSE',
-                              'CPF_DENSE_LW', 'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_JIT', 'CPF_JIT_K',
+                              'CPF_DENSE_LW', 'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_ZYZL_SAVE', 'CPF_RELABEL', 'CPF_JIT', 'CPF_JIT_K',
                               'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_PAIRS'])
     for name in release:
         assert lib.cpf_set_tuning(name.encode(), b'1') == 0 and lib.cpf_set_tuning(name.encode(), None) == 0, name

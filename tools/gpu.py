@@ -50,7 +50,7 @@ def configs():
 
 
 TUNING = ('CPF_SPLIT', 'CPF_PSTORE', 'CPF_MSTORE', 'CPF_KSPEC', 'CPF_PAIRS', 'CPF_LONE', 'CPF_PRIO', 'CPF_LW', 'CPF_GROUP', 'CPF_DENSE', 'CPF_DENSE_LW',
-          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3', 'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_PAIRS', 'CPF_ZYZ3_RES', 'CPF_ZYZ3_STAMPS', 'CPF_ZYZ3_DEFS')
+          'CPF_DENSE_SPECIALISED', 'CPF_DENSE_FOLD', 'CPF_ZYZ', 'CPF_ZYZL', 'CPF_ZYZL_SAVE', 'CPF_RELABEL', 'CPF_FORCE_GENERIC', 'CPF_JIT', 'CPF_JIT_K', 'CPF_NO_AOT3', 'CPF_ZYZ3', 'CPF_ZYZ3_M', 'CPF_ZYZ3_PAIRS', 'CPF_ZYZ3_RES', 'CPF_ZYZ3_STAMPS', 'CPF_ZYZ3_DEFS')
 
 
 def sync_tuning():
