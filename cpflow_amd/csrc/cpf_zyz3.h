@@ -276,6 +276,93 @@ __device__ __forceinline__ void z3_products(f2 v, f2 pre, f2 pim, f2& px, f2& py
             "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
             : "=&v"(px), "=&v"(py) : "v"(v), "v"(pre), "v"(pim));
 }
+// ---- A whole block of the gradient half in ONE statement (round 6, second pass).  Between two dependent asm statements the compiler
+// puts an s_nop 0 of its own (it cannot see what the first one wrote): a block made of four statements carried two of them on 19
+// instructions.  The live matrix sits in the FIXED registers v[2:3] and the partner values in v[4:5] (re) / v[6:7] (im), so that one
+// statement can use the halves (DPP) and the pairs (packed) of the same registers (see z3_unapply_block).
+#ifndef CPF_Z3_FUSED
+#define CPF_Z3_FUSED 1           // A/B: 0 = the four statements per block of the first pass
+#endif
+#ifndef CPF_Z3_FUSED_A
+#define CPF_Z3_FUSED_A CPF_Z3_FUSED
+#endif
+#ifndef CPF_Z3_FUSED_B
+#define CPF_Z3_FUSED_B CPF_Z3_FUSED
+#endif
+// wave A: shares of block B from the cotangent w = v[2:3] and psi(s_B)'s partner values v[4:7]; U = conj(w) o (its .y is the |11> share);
+// then (unless LAST) the partner values of on = psi(s_{B-1}) on the NEXT block's qubits (FA, FB) arrive while the block's stages
+// (QA then QB, un-applied: -t) run on w; then w <- conj(d) w.  No wait state needed: w was last written six instructions before its
+// first DPP read, and two moves stand between the stages.
+template <int QA, int QB, int FA, int FB, bool LAST>
+__device__ __forceinline__ void z3_grad_block_a(float& w0, float& w1, float& pr0, float& pr1, float& pi0, float& pi1, f2 o, f2 on, f2 d, float ta, float tb,
+                                                f2& PX, f2& PY, f2& U) {
+    f2 t;
+#define CPF_Z3_GA_HEAD                                                                                                         \
+        "v_pk_mul_f32 %0, v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"                           \
+        "v_pk_mul_f32 %1, v[2:3], v[6:7] op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"                           \
+        "v_pk_fma_f32 %0, v[2:3], v[6:7], %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                                             \
+        "v_pk_fma_f32 %1, v[2:3], v[4:5], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"               \
+        "v_pk_mul_f32 %2, v[2:3], %10 op_sel_hi:[0,1]\n\t"                                                                     \
+        "v_pk_fma_f32 %2, v[2:3], %10, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t"
+#define CPF_Z3_GA_TAIL                                                                                                         \
+        "v_pk_mul_f32 %3, %13, v[2:3] op_sel_hi:[0,1]\n\t"                                                                     \
+        "v_pk_fma_f32 v[2:3], %13, v[2:3], %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+#define CPF_Z3_GA_OPS                                                                                                          \
+        : "=&v"(PX), "=&v"(PY), "=&v"(U), "=&v"(t), "+{v2}"(w0), "+{v3}"(w1), "+{v4}"(pr0), "+{v5}"(pr1), "+{v6}"(pi0), "+{v7}"(pi1)  \
+        : "v"(o), "v"(on.x), "v"(on.y), "v"(d), "v"(ta), "v"(tb)
+#define CPF_Z3_BODY(CA, CB, GA, GB)                                                                                            \
+    if constexpr (LAST)                                                                                                        \
+        asm(CPF_Z3_GA_HEAD                                                                                                     \
+            "v_fmac_f32_dpp v2, v2, -%14 " CA CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%14 " CA CPF_Z3_DPPT "s_nop 0\n\t"          \
+            "v_fmac_f32_dpp v2, v2, -%15 " CB CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%15 " CB CPF_Z3_DPPT                        \
+            CPF_Z3_GA_TAIL CPF_Z3_GA_OPS);                                                                                     \
+    else                                                                                                                       \
+        asm(CPF_Z3_GA_HEAD                                                                                                     \
+            "v_mov_b32_dpp v4, %11 " GA CPF_Z3_DPPT "v_mov_b32_dpp v6, %12 " GA CPF_Z3_DPPT                                    \
+            "v_fmac_f32_dpp v2, v2, -%14 " CA CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%14 " CA CPF_Z3_DPPT                        \
+            "v_mov_b32_dpp v5, %11 " GB CPF_Z3_DPPT "v_mov_b32_dpp v7, %12 " GB CPF_Z3_DPPT                                    \
+            "v_fmac_f32_dpp v2, v2, -%15 " CB CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, -%15 " CB CPF_Z3_DPPT                        \
+            CPF_Z3_GA_TAIL CPF_Z3_GA_OPS);
+    if constexpr (QA == 0 && QB == 1) { CPF_Z3_PAIRS6(F, CPF_Z3_C0, CPF_Z3_C1) }
+    else if constexpr (QA == 0 && QB == 2) { CPF_Z3_PAIRS6(F, CPF_Z3_C0, CPF_Z3_C2) }
+    else if constexpr (QA == 1 && QB == 0) { CPF_Z3_PAIRS6(F, CPF_Z3_C1, CPF_Z3_C0) }
+    else if constexpr (QA == 1 && QB == 2) { CPF_Z3_PAIRS6(F, CPF_Z3_C1, CPF_Z3_C2) }
+    else if constexpr (QA == 2 && QB == 0) { CPF_Z3_PAIRS6(F, CPF_Z3_C2, CPF_Z3_C0) }
+    else { CPF_Z3_PAIRS6(F, CPF_Z3_C2, CPF_Z3_C1) }
+#undef CPF_Z3_BODY
+#undef CPF_Z3_GA_OPS
+#undef CPF_Z3_GA_TAIL
+#undef CPF_Z3_GA_HEAD
+}
+// wave B: psi' = v[2:3] <- d psi', the partner values of o = W(s_B) on the block's qubits arrive in v[4:7] while its stages (QA then QB)
+// run on psi' (the two moves in front of each stage are its wait states), then the four products and U = conj(o) psi'.
+template <int QA, int QB>
+__device__ __forceinline__ void z3_grad_block_b(float& p0, float& p1, f2 d, f2 o, float ta, float tb, f2& PX, f2& PY, f2& U) {
+    f2 t;
+    float q4, q5, q6, q7;                                      // v[4:7]: the partner values, dead after the statement
+#define CPF_Z3_BODY(CA, CB)                                                                                                    \
+    asm("v_pk_mul_f32 %3, %10, v[2:3] op_sel_hi:[0,1]\n\t"                                                                      \
+        "v_pk_fma_f32 v[2:3], %10, v[2:3], %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"                              \
+        "v_mov_b32_dpp v4, %11 " CA CPF_Z3_DPPT "v_mov_b32_dpp v6, %12 " CA CPF_Z3_DPPT                                          \
+        "v_fmac_f32_dpp v2, v2, %13 " CA CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, %13 " CA CPF_Z3_DPPT                                \
+        "v_mov_b32_dpp v5, %11 " CB CPF_Z3_DPPT "v_mov_b32_dpp v7, %12 " CB CPF_Z3_DPPT                                          \
+        "v_fmac_f32_dpp v2, v2, %14 " CB CPF_Z3_DPPT "v_fmac_f32_dpp v3, v3, %14 " CB CPF_Z3_DPPT                              \
+        "v_pk_mul_f32 %0, v[2:3], v[6:7] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"                           \
+        "v_pk_mul_f32 %1, v[2:3], v[6:7] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                                     \
+        "v_pk_fma_f32 %0, v[2:3], v[4:5], %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                                             \
+        "v_pk_fma_f32 %1, v[2:3], v[4:5], %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                                             \
+        "v_pk_mul_f32 %2, %15, v[2:3] op_sel_hi:[0,1]\n\t"                                                                     \
+        "v_pk_fma_f32 %2, %15, v[2:3], %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"                                     \
+        : "=&v"(PX), "=&v"(PY), "=&v"(U), "=&v"(t), "+{v2}"(p0), "+{v3}"(p1), "=&{v4}"(q4), "=&{v5}"(q5), "=&{v6}"(q6), "=&{v7}"(q7)  \
+        : "v"(d), "v"(o.x), "v"(o.y), "v"(ta), "v"(tb), "v"(o));
+    if constexpr (QA == 0 && QB == 1) { CPF_Z3_BODY(CPF_Z3_C0, CPF_Z3_C1) }
+    else if constexpr (QA == 0 && QB == 2) { CPF_Z3_BODY(CPF_Z3_C0, CPF_Z3_C2) }
+    else if constexpr (QA == 1 && QB == 0) { CPF_Z3_BODY(CPF_Z3_C1, CPF_Z3_C0) }
+    else if constexpr (QA == 1 && QB == 2) { CPF_Z3_BODY(CPF_Z3_C1, CPF_Z3_C2) }
+    else if constexpr (QA == 2 && QB == 0) { CPF_Z3_BODY(CPF_Z3_C2, CPF_Z3_C0) }
+    else { CPF_Z3_BODY(CPF_Z3_C2, CPF_Z3_C1) }
+#undef CPF_Z3_BODY
+}
 // The penalty of one CP angle and its slope (penalty.py:44-71): cpf_device.h penalty_lds (since round 6 the compare-free form this
 // kernel introduced serves every kernel).
 __device__ __forceinline__ float z3_penalty(const float* tab, int pen_kind, float ang, float& slope) { return penalty_lds(tab, pen_kind, ang, slope); }
@@ -503,8 +590,10 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // sample's results when they differ.  The step loops are only correct while the compiler keeps ONE barrier per phase and wave: a
     // loop it split by lanes ran its s_barrier once per group of lanes and the two waves silently lost step (see "No branch on the
     // lane ..." above) - with the count, every instance of every shape checks itself on every launch.
+    // (readfirstlane: free where the count already sits in a scalar register - every instance but those with fewer than three blocks in
+    // wave B, where the count passes a divergent join and hipcc's backend aborted on the "+s" operand: "illegal VGPR to SGPR copy")
     unsigned nbar = 0;
-    auto barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_add_u32 %0, %0, 1" : "+s"(nbar) :: "memory", "scc"); };
+    auto barrier = [&]() __attribute__((always_inline)) { nbar = __builtin_amdgcn_readfirstlane(nbar); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_add_u32 %0, %0, 1" : "+s"(nbar) :: "memory", "scc"); };
     // static structure: qubit of side w (block w >> 1, side w & 1)
     auto qubit_of = [&](int w) {
         int r = 0;
@@ -830,12 +919,30 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
             // partner values arrive.  19 instructions, no s_nop.
             f2 pre, pim;                                     // (re up, re dn), (im up, im dn) of psi(s_B) at the partner lanes
             z3_fetch<PL::v[2 * ((M - 1) % LL)], PL::v[2 * ((M - 1) % LL) + 1]>(own[M], pre, pim);
+#if CPF_Z3_FUSED_A
+            {
+                float w0 = w.x, w1 = w.y, pr0 = pre.x, pr1 = pre.y, pi0 = pim.x, pi1 = pim.y;       // in v[2:7] inside every block's statement
+                static_for([&](auto bb) __attribute__((always_inline)) {
+                    constexpr int B = M - 1 - decltype(bb)::value, J = B % LL, JN = (B > 0 ? B - 1 : 0) % LL;
+                    constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
+                    // Im of conj(w) psi[partner] and MINUS its real part for both qubits at once (the Py rows hold unsigned shares: the sign
+                    // of the lane's bit is applied by the row sums, see row_consts); Im(conj(w) psi) at the lane
+                    f2 PX, PY, U;
+                    z3_grad_block_a<DN, UP, PL::v[2 * JN], PL::v[2 * JN + 1], B == 0>(w0, w1, pr0, pr1, pi0, pi1, own[B + 1], own[B], f2{ent[B].x, ent[B].y},
+                                                                                       ent[B].w, ent[B].z, PX, PY, U);
+                    pb[B][0] = PX.x;
+                    pb[B][ZYZ3_ROW] = PY.x;
+                    pb[B][2 * ZYZ3_ROW] = PX.y;
+                    pb[B][3 * ZYZ3_ROW] = PY.y;
+                    pb[B][4 * ZYZ3_ROW] = U.y;
+                }, typename make_iseq<M>::type{});
+                w = f2{w0, w1};
+            }
+#else
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = M - 1 - decltype(bb)::value, J = B % LL;
                 constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
                 const f2 o = own[B + 1];
-                // Im of conj(w) psi[partner] and MINUS its real part for both qubits at once (the Py rows hold unsigned shares: the sign of
-                // the lane's bit is applied by the row sums, see row_consts); Im(conj(w) psi) at the lane
                 f2 PX, PY;
                 z3_products<false>(w, pre, pim, PX, PY);
                 pb[B][0] = PX.x;
@@ -849,6 +956,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 } else z3_stage2<DN, UP, true, 0>(w, ent[B].w, ent[B].z);
                 w = z3_cmul_conj(f2{ent[B].x, ent[B].y}, w);
             }, typename make_iseq<M>::type{});
+#endif
             {   // the surface slice s_-1: all three qubits, and the |11> sum of block 0.  The partner is taken of the cotangent (the sums run
                 // over all lanes, so conj(w) psi[partner] and conj(w[partner]) psi add up to the same): ONE complex product per qubit
                 // gives the Py share (real part; its sign comes with the row sums) and the Px share (imaginary part)
@@ -1134,6 +1242,21 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
         // ================= gradient half: blocks M .. K-1 applied to psi' = conj(f) psi (the scalar moves onto psi once), W(s_b) at hand
         {
             f2 pp = z3_cmul_conj(f2{-a.inv_dim2 * tr, -a.inv_dim2 * ti}, psi_c);
+            if constexpr (CPF_Z3_FUSED_B != 0) {
+            float p0 = pp.x, p1 = pp.y;                                           // in v[2:3] inside every block's statement
+            static_for([&](auto bb) __attribute__((always_inline)) {
+                constexpr int B = M + decltype(bb)::value, J = B % LL;
+                constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
+                // the roles swapped: Im / Re of conj(W[partner]) psi' (unsigned: the row sums sign the Py rows), Im(conj(W) psi') at the lane
+                f2 PX, PY, U;
+                z3_grad_block_b<UP, DN>(p0, p1, f2{ent[B - M].x, ent[B - M].y}, own[B - M + 1], ent[B - M].z, ent[B - M].w, PX, PY, U);
+                pb[B - M][0] = PX.x;
+                pb[B - M][ZYZ3_ROW] = PY.x;
+                pb[B - M][2 * ZYZ3_ROW] = PX.y;
+                pb[B - M][3 * ZYZ3_ROW] = PY.y;
+                pb[B - M][4 * ZYZ3_ROW] = U.y;
+            }, typename make_iseq<K - M>::type{});
+            } else {
             static_for([&](auto bb) __attribute__((always_inline)) {
                 constexpr int B = M + decltype(bb)::value, J = B % LL;
                 constexpr int UP = PL::v[2 * J], DN = PL::v[2 * J + 1];
@@ -1149,6 +1272,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
                 pb[B - M][3 * ZYZ3_ROW] = PY.y;
                 pb[B - M][4 * ZYZ3_ROW] = z3_cmul_conj(o, pp).y;
             }, typename make_iseq<K - M>::type{});
+            }
         }
         lds_fence();
 #pragma unroll

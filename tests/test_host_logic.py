@@ -276,6 +276,14 @@ def test_jit_precompile_cache_and_forbid(tmp_path, monkeypatch):
     assert len(lines) == 2 and all('[built]' in x and '(hipcc)' in x for x in lines), lines
     assert lines[0].startswith('zyz3/jit(hipcc) waves=2 K cut=2 [built] cpf::zyz3_body<') and lines[1].startswith('zyz3/jit(hipcc) waves=2 K cut=1 [built] '), lines
     assert (os.stat(tmp_path / 'cache').st_mode & 0o077) == 0          # private directory
+    # three blocks, one of them wave A's: two blocks in wave B.  Round 6's first pass made hipcc's backend abort on such instances
+    # ("illegal VGPR to SGPR copy" on the barrier counter's scalar operand) and the build fell back to hiprtc's slower object
+    # without a word; the offline compiler must build every instance
+    code3 = code.replace("'yz', 5, 64", "'xyz', 3, 64")
+    r3 = subprocess.run([sys.executable, '-c', code3], env=dict(os.environ, CPF_JIT_CACHE=str(tmp_path / 'cache')), capture_output=True, text=True, cwd=ROOT)
+    assert r3.returncode == 0, r3.stderr
+    lines3 = json.loads(r3.stdout.strip().splitlines()[-1])
+    assert lines3 and all(x.startswith('zyz3/jit(hipcc) waves=2 K cut=1 [built]') for x in lines3), lines3
     r = run({'CPF_JIT_FORBID_COMPILE': '1'})                           # now served from the cache
     assert r.returncode == 0 and all('[cached]' in x for x in json.loads(r.stdout.strip().splitlines()[-1]))
 
