@@ -101,7 +101,7 @@ struct KArgs {
     float* hist_loss;          // [S][T] or null
     float* out_grad;           // MODE_LOSS_GRAD: [S][P] or null
     float2* out_U;             // MODE_UNITARY: [S][N][N]
-    int prio;                  // two-ended kernel: raise the longer wave's issue priority (launches that leave SIMDs unsaturated)
+    int prio;                  // two-ended kernels: bit 0 = raise the longer wave's issue priority (launches that leave SIMDs unsaturated); bit 1 (cpf_zyz3.h) = start the workgroups' step loops out of phase
     int nsamples;              // samples of this launch (kernels with several samples per workgroup mask the tail)
     int lone;                  // two-ended kernel, K from the plan: at most one sample per CU - balance the two waves' chains
     int group;                 // one-wave layered kernels: samples per workgroup (0 / 1: one; cpf_layered.h layered_body)

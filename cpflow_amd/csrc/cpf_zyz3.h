@@ -280,8 +280,27 @@ __device__ __forceinline__ void z3_products(f2 v, f2 pre, f2 pim, f2& px, f2& py
 // puts an s_nop 0 of its own (it cannot see what the first one wrote): a block made of four statements carried two of them on 19
 // instructions.  The live matrix sits in the FIXED registers v[2:3] and the partner values in v[4:5] (re) / v[6:7] (im), so that one
 // statement can use the halves (DPP) and the pairs (packed) of the same registers (see z3_unapply_block).
+// Launches whose workgroups are all resident run 2048 waves in lock-step through phases of very different density (owner phases: a few
+// lanes; sweeps: all of them), and the chip's clock follows the current swing (section "Round 6" of DESIGN.md).  STAGGER = G > 1: the
+// workgroups start their step loops G-fold out of phase (group g sleeps g / G of a step once, in front of the loop), so that dense
+// and sparse phases overlap across the chip - and on a SIMD shared by a wave A and a wave B of different samples.  Measured: whether
+// the groups really sleep makes no difference (bit on / off: equal to 0.1 %), so the clock does not follow the swing but the mean power;
+// what the few instructions in front of the loop do change is the code the compiler makes of wave A's loop, worth a steady 0.5 % with
+// the four-statement gradient blocks on three boxes (4.00 - 4.02 against 4.02 - 4.04 ms) and -1 % with the fused ones.  Kept for that.
+#ifndef CPF_Z3_STAGGER
+#define CPF_Z3_STAGGER 4         // groups (0 / 1: none); the host asks for it with bit 1 of KArgs::prio (bit 0: wave B's issue priority)
+#endif
+#ifndef CPF_Z3_STAGGER_SHIFT
+#define CPF_Z3_STAGGER_SHIFT 3   // group = (workgroup >> SHIFT) % G: workgroups go round the 8 XCDs first
+#endif
+#ifndef CPF_Z3_STAGGER_STEP
+#define CPF_Z3_STAGGER_STEP 76   // one step in units of 64 clocks (config 2: 4900 clocks)
+#endif
+// Measured (profiles/r06_cfg2_levers_ab.txt section 13): 707 + 512 -> 691 + 505 instructions per sample-step and NOT faster - config 2's
+// launch is power-limited: the fused form's best launches take 3.96 ms, but its sustained mean over 150 launches is 4.06 - 4.08 (the
+// clock dips in a third of them) against 4.02 - 4.04 steady for the four-statement form, on three boxes.  Off by default.
 #ifndef CPF_Z3_FUSED
-#define CPF_Z3_FUSED 1           // A/B: 0 = the four statements per block of the first pass
+#define CPF_Z3_FUSED 0           // 1 = one statement per gradient block, 0 = the four statements per block of the first pass
 #endif
 #ifndef CPF_Z3_FUSED_A
 #define CPF_Z3_FUSED_A CPF_Z3_FUSED
@@ -583,7 +602,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     auto phase_prio = [&](auto code, auto ph) __attribute__((always_inline)) {
         constexpr int C = decltype(code)::value, PH = decltype(ph)::value;
         constexpr int d[3] = {(C / 100) % 10, (C / 10) % 10, C % 10};
-        if constexpr (d[PH] != d[(PH + 2) % 3]) { if (a.prio) __builtin_amdgcn_s_setprio(d[PH]); }
+        if constexpr (d[PH] != d[(PH + 2) % 3]) { if (a.prio & 1) __builtin_amdgcn_s_setprio(d[PH]); }
     };
     auto lds_fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
     // Every barrier a wave passes is counted (one scalar add); the two waves compare their counts after the last step and poison the
@@ -842,7 +861,15 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_STAMPS
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
-        if (a.prio && CPF_Z3_PRIO_A / 100 != 0) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_A / 100) % 10);
+        if ((a.prio & 1) && CPF_Z3_PRIO_A / 100 != 0) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_A / 100) % 10);
+#if CPF_Z3_STAGGER > 1
+        if (a.prio & 2) {
+            static_for([&](auto gg) __attribute__((always_inline)) {
+                constexpr int G = decltype(gg)::value;
+                if (G > 0 && (int)((blockIdx.x >> CPF_Z3_STAGGER_SHIFT) % CPF_Z3_STAGGER) == G) __builtin_amdgcn_s_sleep(CPF_Z3_STAGGER_STEP * G / CPF_Z3_STAGGER);
+            }, typename make_iseq<CPF_Z3_STAGGER>::type{});
+        }
+#endif
         for (int it = 0; it < iters; it++) {
             phase_prio(ic<CPF_Z3_PRIO_A>{}, ic<0>{});
             if (owner_a) {   // the surface gates' owner phase, beside wave B's: chain rule for the step just closed, Adam, (cos, sin), matrices
@@ -1013,7 +1040,7 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
     // While every workgroup of the launch is resident (a.prio, set by the host) wave B gets the higher issue priority on the SIMD it
     // shares with a wave A of another sample (config 2, cut 4: 5.35 -> 4.74 ms; raising wave A's in its gradient half on top: 4.92).
     // In a launch of several rounds of workgroups the priority starves the other waves (2048 samples 11.6 -> 14.8 ms).
-    if (a.prio) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_B / 100) % 10);
+    if (a.prio & 1) __builtin_amdgcn_s_setprio((CPF_Z3_PRIO_B / 100) % 10);
 #endif
     // the owner wave and, in it, the sample and the item of this lane
     const bool owner_wave = pair == 0;
@@ -1111,6 +1138,14 @@ __device__ __forceinline__ void zyz3_body(const KArgs& a) {
 #ifdef CPF_HWID
     unsigned long long clk0 = 0, rt0 = 0;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
+#endif
+#if CPF_Z3_STAGGER > 1
+    if (a.prio & 2) {
+        static_for([&](auto gg) __attribute__((always_inline)) {
+        constexpr int G = decltype(gg)::value;
+        if (G > 0 && (int)((blockIdx.x >> CPF_Z3_STAGGER_SHIFT) % CPF_Z3_STAGGER) == G) __builtin_amdgcn_s_sleep(CPF_Z3_STAGGER_STEP * G / CPF_Z3_STAGGER);
+        }, typename make_iseq<CPF_Z3_STAGGER>::type{});
+    }
 #endif
     for (int it = 0; it < iters; it++) {
         phase_prio(ic<CPF_Z3_PRIO_B>{}, ic<0>{});

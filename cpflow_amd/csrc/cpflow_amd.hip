@@ -873,6 +873,11 @@ bool try_zyz3(cpf_plan* plan, const cpf::KArgs& a, int64_t S, hipStream_t stream
     cpf::KArgs args = a;
     args.prio = zyz3_all_resident(plan, S);                  // every workgroup resident: wave B gets the higher issue priority
     { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = p[0] == '1'; }
+    // ... and from three samples per CU on (waves of different samples share SIMDs) the workgroups start their step loops four-fold out
+    // of phase (cpf_zyz3.h CPF_Z3_STAGGER: 2048 waves in lock-step through dense and sparse phases make the clock dip; sustained means of
+    // 150 launches: config 2 4.06 -> 3.98 ms; 1536 samples, and 512 / 256 where the bit is not set, unchanged; config 3's 512: +0.6 % if set)
+    if (zyz3_all_resident(plan, S) && zyz3_per_cu(plan, S) >= 3) args.prio |= 2;
+    { const TuneVal p = tuning("CPF_PRIO"); if (p) args.prio = atoi(p.s.c_str()) & 3; }      // A/B: the whole mask (1 = priority only, 2 = stagger only, 3 = both)
     if (!defs && !stamps) {
         hipError_t e = hipSuccess;
         if (cpf_zyz3_launch_aot(rot, plan->K, M, pairs, plan->layer_ud, args, S, lds, stream, &e)) {

@@ -120,7 +120,7 @@ def cmd_knobs(args):
     init = eng.initial_angles(0, S)
     res, var, stats = {c: [] for c in combos}, {}, {}
     keys = {kv.split('=', 1)[0] for c in combos for kv in c.split(',')}
-    for _ in range(5):
+    for _ in range(int(os.environ.get('REPS', '5'))):
         for c in combos:
             for k in keys:                       # a switch one combination sets must not leak into the next
                 os.environ.pop(k, None)
@@ -134,7 +134,7 @@ def cmd_knobs(args):
             var[c] = eng.last_variant()
             stats[c] = (int(out['passed'].sum()), int(out['cz'][out['passed']].min()) if out['passed'].any() else -1)
     for c in combos:
-        print(f'{cfg} S={S} {c:40s} min {min(res[c]):.3f} median {sorted(res[c])[len(res[c]) // 2]:.3f} ms  {S * T / min(res[c]) * 1e3:.3e}/s  [{var[c]}] passed/minCZ {stats[c]}', flush=True)
+        print(f'{cfg} S={S} {c:40s} min {min(res[c]):.3f} median {sorted(res[c])[len(res[c]) // 2]:.3f} mean {sum(res[c]) / len(res[c]):.3f} ms  {S * T / min(res[c]) * 1e3:.3e}/s  [{var[c]}] passed/minCZ {stats[c]}', flush=True)
 
 
 def cmd_ablib(args):
