@@ -285,7 +285,8 @@ __device__ __forceinline__ void z3_products(f2 v, f2 pre, f2 pim, f2& px, f2& py
 // workgroups start their step loops G-fold out of phase (group g sleeps g / G of a step once, in front of the loop), so that dense
 // and sparse phases overlap across the chip - and on a SIMD shared by a wave A and a wave B of different samples.  Measured: whether
 // the groups really sleep makes no difference (bit on / off: equal to 0.1 %), so the clock does not follow the swing but the mean power;
-// what the few instructions in front of the loop do change is the code the compiler makes of wave A's loop, worth a steady 0.5 % with
+// what the few instructions in front of the loops do change is the generated code, slightly (709 + 516 instructions in the step loops
+// instead of 707 + 512, a second exit) - and that is worth a steady 0.5 %, unexplained and reproducible on four boxes, with
 // the four-statement gradient blocks on three boxes (4.00 - 4.02 against 4.02 - 4.04 ms) and -1 % with the fused ones.  Kept for that.
 #ifndef CPF_Z3_STAGGER
 #define CPF_Z3_STAGGER 4         // groups (0 / 1: none); the host asks for it with bit 1 of KArgs::prio (bit 0: wave B's issue priority)

@@ -57,7 +57,7 @@ def step_loops(lines, kernel):
     name, key = mangled_key(kernel)
     # the mangled name carries the template arguments as Li<n>E tokens, the layer pack between J and E
     start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\S*:', l) and name in l and ('I' + key + 'E') in l.split(':')[0].replace('J', ''))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith('s_endpgm'))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end')) - 1      # (a kernel may hold several s_endpgm: the end of the function, not the first of them)
     # loops = backward branches; keep the outermost ones that hold an s_barrier or, failing that, the largest one
     raw = []
     body = [l.split(';')[0].strip() for l in lines[start + 1:end + 1]]

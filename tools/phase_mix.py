@@ -15,7 +15,7 @@ def main():
     path, key = sys.argv[1], sys.argv[2]
     lines = open(path).read().splitlines()
     start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\S*:', l) and key in l)
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith('s_endpgm'))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end')) - 1      # (a kernel may hold several s_endpgm: the end of the function, not the first of them)
     phase, mixes, order = 'prologue', collections.defaultdict(collections.Counter), ['prologue']
     for l in lines[start + 1:end + 1]:
         m = re.search(r'; CPF_MARK (\w+)', l)
