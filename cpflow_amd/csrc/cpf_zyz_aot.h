@@ -20,6 +20,11 @@ bool cpf_zyz_has_aot(int nq, int lw, int rot, const std::vector<int>& ud);
 #ifndef CPF_ZYZL_AOT_SAVE
 #define CPF_ZYZL_AOT_SAVE 2      // what 256 registers per lane hold beside the kernel's own ~190 (3: 123 spills, 5: 223)
 #endif
+#ifndef CPF_ZYZL_AOT_SAVEL
+#define CPF_ZYZL_AOT_SAVEL 0     // + 256 x the layers in front of those whose blocks' input states are kept in LDS (6 KB per sample and layer of 3 blocks):
+                                 // measured with one such layer: 29.09 -> 28.96 ms where two register layers alone give 28.86 -> 28.43 - not shipped
+#endif
+#define CPF_ZYZL_AOT_KEPT_CODE (1 + 16 * CPF_ZYZL_AOT_SAVE + 256 * CPF_ZYZL_AOT_SAVEL)
 int cpf_zyzl_launch_aot(int nq, int rot, int nslot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
                         hipStream_t stream, hipError_t* err);
 bool cpf_zyzl_has_aot(int nq, int rot, int nslot, const std::vector<int>& ud);

@@ -51,13 +51,13 @@ const std::vector<int> CHAIN4_RELABELLED = {0, 2, 2, 3, 3, 1};
 
 // nslot: items per lane + 16 x (layers whose blocks' input states stay in registers: cpf_zyzl.h SAVE)
 bool cpf_zyzl_has_aot(int nq, int rot, int nslot, const std::vector<int>& ud) {
-    return rot == CPF_DENSE_AOT_ROT && nq == 4 && (nslot == 1 || nslot == 1 + 16 * CPF_ZYZL_AOT_SAVE) && ud == CHAIN4_RELABELLED;
+    return rot == CPF_DENSE_AOT_ROT && nq == 4 && (nslot == 1 || nslot == CPF_ZYZL_AOT_KEPT_CODE) && ud == CHAIN4_RELABELLED;
 }
 
 int cpf_zyzl_launch_aot(int nq, int rot, int nslot, const std::vector<int>& ud, const cpf::ZyzlArgs& za, unsigned grid, unsigned block, size_t lds,
                         hipStream_t stream, hipError_t* err) {
     if (!cpf_zyzl_has_aot(nq, rot, nslot, ud)) return 0;
     if (nslot == 1) *err = run_l<4, CPF_DENSE_AOT_ROT, 1, 0, 2, 2, 3, 3, 1>(za, grid, block, lds, stream);
-    else *err = run_l<4, CPF_DENSE_AOT_ROT, 1 + 16 * CPF_ZYZL_AOT_SAVE, 0, 2, 2, 3, 3, 1>(za, grid, block, lds, stream);
+    else *err = run_l<4, CPF_DENSE_AOT_ROT, CPF_ZYZL_AOT_KEPT_CODE, 0, 2, 2, 3, 3, 1>(za, grid, block, lds, stream);
     return 1;
 }

@@ -25,9 +25,10 @@ constexpr int ZYZL_TAB_FLOATS = 20;
 struct ZyzlArgs { KArgs k; const ZyzSideInfo* sides; int K, n_rot; };
 
 struct ZyzlLds {                                     // float offsets, per sample; [0, 28) = penalty table
-    int side, stat, btab, surfm, lfin, fw, red, sums, gsurf, total;
+    int side, stat, btab, surfm, lfin, fw, red, sums, gsurf, keptl, total;
     __host__ __device__ static constexpr int up4(int x) { return (x + 3) & ~3; }
-    __host__ __device__ ZyzlLds(int K, int nq, int wps = 1) {
+    // keptl_states: block input states kept in LDS from the forward sweep (zyzl_body SAVEL; 64 lanes x 8 floats each)
+    __host__ __device__ ZyzlLds(int K, int nq, int wps = 1, int keptl_states = 0) {
         side = PEN_FLOATS;                     // 2 K x {t, sc, l0, l1, f, -}: the side records
         stat = side + 16 * K;                  // (2 K + nq) x {prev, qubit, -, -, later masks}: static structure (cpf_zyz.h ZyzSideInfo)
         btab = stat + 12 * (2 * K + nq);       // K per-block tables
@@ -37,7 +38,8 @@ struct ZyzlLds {                                     // float offsets, per sampl
         red = fw + 8;                          // [wps][3]: loss / penalty partial sums of the waves
         sums = red + 16;                       // [wps][K][32]: generator sums, reduce8_rows slabs
         gsurf = sums + wps * K * 32;           // [wps][NBATCH][32]
-        total = up4(gsurf + wps * ((3 * nq + 7) / 8) * 32);
+        keptl = up4(gsurf + wps * ((3 * nq + 7) / 8) * 32);
+        total = keptl + keptl_states * 512;
     }
 };
 
@@ -365,21 +367,24 @@ __device__ __forceinline__ void zl_wave_sum3(float& re, float& im, float& pen, b
 // psi from there instead of un-applying the blocks from it (zl_bwd_saved) - config 4: 15 of 24 blocks, 16 of ~110 instructions each.
 template <int NQ, int LW, int ROT, int NSLOT_SAVE, int... UD>
 __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
-    constexpr int NSLOT = NSLOT_SAVE & 15, SAVE = NSLOT_SAVE >> 4;
+    constexpr int NSLOT = NSLOT_SAVE & 15, SAVE = (NSLOT_SAVE >> 4) & 15, SAVEL = (NSLOT_SAVE >> 8) & 15;
     using L = Lay<NQ, LW>;
     constexpr int WPS = L::WPS, THREADS = L::THREADS;
     using PL = PairList<UD...>;
     constexpr int LL = sizeof...(UD) / 2;
     static_assert(LL > 0 && ROT != 0, "the ZYZ-form kernel is specialised on the layer and the rotation string");
     constexpr int E = L::E, NS = 3 * NQ, NBATCH = (NS + 7) / 8;
-    constexpr int NSAVE = SAVE * LL;                       // blocks K - NSAVE .. K - 1
+    constexpr int NSAVE = SAVE * LL;                       // blocks K - NSAVE .. K - 1: input states in registers
+    constexpr int NSL = SAVEL * LL;                        // blocks K - NSAVE - NSL .. K - NSAVE - 1: input states in LDS (when the registers are full:
+                                                           // two ds_write_b128 forward and two ds_read_b128 backward instead of 16 instructions)
+    static_assert(SAVEL == 0 || (SAVE > 0 && E == 4), "LDS-kept states come in front of register-kept ones");
     static_assert(SAVE == 0 || (WPS == 1 && E <= 4 && NSAVE * E * 2 <= 160), "kept states: one wave per sample, at most 160 registers of them");
     constexpr int NR = ROT & 15, ENT = (ROT >> 16) & 3, NBP = 2 * NR + (ENT == 0 ? 1 : 0);
     static_assert(NR >= 1 && NR <= 3 && ENT <= 1, "1..3 rotation letters, CP or CZ blocks");
     const KArgs& a = za.k;
     extern __shared__ __attribute__((aligned(16))) float smem_wg[];
     const int P = a.P, K = za.K;
-    const ZyzlLds lds(K, NQ, WPS);
+    const ZyzlLds lds(K, NQ, WPS, NSL);
     const int sub = WPS == 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int tid = WPS == 1 ? ((int)threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63;
     const int wave = WPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,7 +410,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
     const char* tbase = reinterpret_cast<const char*>(a.target);
     // 4 qubits (4 amplitudes per lane): the lane's target elements stay in registers for the whole run (8 registers of a kernel that may
     // use 256: two waves per SIMD at most) instead of four global loads in the loss and four more before the backward sweep of every step
-    constexpr bool TREG = E <= 4 && (NSLOT_SAVE >> 4) == 0;      // (the instance that keeps states has no registers to spare: it re-reads)
+    constexpr bool TREG = E <= 4 && SAVE == 0;      // (the instance that keeps states has no registers to spare: it re-reads)
     float2 treg[TREG ? E : 1];
     if constexpr (TREG) {
 #pragma unroll
@@ -502,6 +507,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 
     f2 psi[E], cot[E];
     f2 kept[NSAVE > 0 ? NSAVE : 1][E];
+    float4* keptl = reinterpret_cast<float4*>(smem + lds.keptl) + lane;          // [state][half][lane]: conflict-free ds_*_b128
     float best = 0.f, first = 0.f;
     const int iters = a.T > 0 ? a.T : 1;
     for (int it = 0; it < iters; it++) {
@@ -642,7 +648,15 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 gate_fence<L>();
                 b++;
             };
-            for (int full = K / LL - SAVE; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
+            for (int full = K / LL - SAVE - SAVEL; full > 0; full--) static_for(fwd_step, typename make_iseq<LL>::type{});
+            if constexpr (SAVEL > 0) {
+                static_for([&](auto ii) __attribute__((always_inline)) {
+                    constexpr int I = decltype(ii)::value;
+                    keptl[(2 * I) * 64] = make_float4(psi[0].x, psi[0].y, psi[1].x, psi[1].y);          // the state in front of block K - NSAVE - NSL + I
+                    keptl[(2 * I + 1) * 64] = make_float4(psi[2].x, psi[2].y, psi[3].x, psi[3].y);
+                    fwd_step(ic<I % LL>{});
+                }, typename make_iseq<NSL>::type{});
+            }
             if constexpr (SAVE > 0) {
                 static_for([&](auto ii) __attribute__((always_inline)) {
                     constexpr int I = decltype(ii)::value;
@@ -785,6 +799,27 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                 }, typename make_iseq<NSAVE>::type{});
 #pragma unroll
                 for (int e = 0; e < E; e++) psi[e] = kept[0][e];             // the state in front of block K - NSAVE: the other layers un-apply from here
+                if constexpr (SAVEL > 0) {
+                    static_for([&](auto ii) __attribute__((always_inline)) {
+                        constexpr int I = NSL - 1 - decltype(ii)::value, J = I % LL, JN = (J + LL - 1) % LL;
+                        const float4 q0 = keptl[(2 * I) * 64], q1 = keptl[(2 * I + 1) * 64];
+                        const ZlRaw cur = nxt;
+                        zl_load_raw<L, PL::v[2 * JN], PL::v[2 * JN + 1]>(nxt, btn, ln);
+                        btn -= ZYZL_TAB_FLOATS;
+                        __builtin_amdgcn_sched_barrier(0);
+                        ZlTab<L, PL::v[2 * J], PL::v[2 * J + 1]> t;
+                        zl_use(t, cur, ln);
+                        const f2 q[E] = {f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, f2{q1.z, q1.w}};
+                        float d8[8];
+                        zl_bwd_saved<L, PL::v[2 * J], PL::v[2 * J + 1]>(psi, q, cot, t, ln, d8);       // psi: the state behind the block
+                        reduce8_rows<true>(d8, sums_b, lane, dst_lane);
+                        sums_b -= 32;
+#pragma unroll
+                        for (int e = 0; e < E; e++) psi[e] = q[e];
+                        gate_fence<L>();
+                        b--;
+                    }, typename make_iseq<NSL>::type{});
+                }
             } else {
                 const int tail = K % LL;                   // blocks beyond the last whole layer come first
                 static_for([&](auto jj) __attribute__((always_inline)) {
@@ -792,7 +827,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                     if (J < tail) bwd_step(jj);
                 }, typename make_iseq<LL>::type{});
             }
-            for (int full = K / LL - SAVE; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
+            for (int full = K / LL - SAVE - SAVEL; full > 0; full--) static_for(bwd_step, typename make_iseq<LL>::type{});
         }
         CPF_MARK(gsurf);
         {   // generator sums of every qubit at the surface state
@@ -856,7 +891,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
                         const int wp = st[0], q = st[1];
                         pzq[sd2] = wp < 0 ? slab_sum(lds.gsurf, NBATCH * 32, (3 * q + 2) >> 3, (3 * q + 2) & 7) : slab_sum(lds.sums, K * 32, wp >> 1, 3 * (wp & 1) + 2);
                     }
-                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], t.cacb, (NSAVE > 0 && b >= K - NSAVE) ? 1.f : t.d0);
+                    t.g[3] = zyz::chain_cp(slab_sum(lds.sums, K * 32, b, 6), pzq[0], pzq[1], t.cacb, (NSAVE > 0 && b >= K - NSAVE - NSL) ? 1.f : t.d0);
                 }
             } else if (t.kind == 1) {
                 const int q = i - 2 * K;
@@ -913,7 +948,7 @@ __device__ __forceinline__ void zyzl_body(const ZyzlArgs& za) {
 // (the instance that keeps states runs two waves per SIMD like the others: its registers, kept states included, must fit 256 per lane -
 // without the second bound the compiler parks the kept states in accumulation registers, 394 in all, and halves the residency)
 template <int NQ, int LW, int ROT, int NSLOT_SAVE, int... UD>
-__global__ __launch_bounds__(256, (NSLOT_SAVE >> 4) != 0 ? 2 : 1) void k_cp_zyzl(const ZyzlArgs za) {
+__global__ __launch_bounds__(256, ((NSLOT_SAVE >> 4) & 15) != 0 ? 2 : 1) void k_cp_zyzl(const ZyzlArgs za) {
     zyzl_body<NQ, LW, ROT, NSLOT_SAVE, UD...>(za);
 }
 

@@ -627,18 +627,20 @@ bool zyzl_wanted(const cpf_plan* plan, int mode, int lw) {
     return e ? e[0] != '0' : (lw == 0 ? plan->NQ >= 4 : (lw == 2 && plan->NQ == 5));
 }
 // Layers whose blocks' input states the forward sweep keeps in registers (cpf_zyzl.h SAVE: the backward sweep does not un-apply those
-// blocks from psi).  Shipped instances only - config 4's shape with at least five whole layers (15 kept states = 120 registers) - so
-// that no run-time built shape gains a variant; CPF_ZYZL_SAVE=0 selects the instance without (parity tests run both).
+// blocks from psi) - CPF_ZYZL_AOT_SAVE layers, what the registers hold - and, in front of them, CPF_ZYZL_AOT_SAVEL layers in LDS.
+// Shipped instances only - config 4's shape with at least that many whole layers - so that no run-time built shape gains a variant;
+// CPF_ZYZL_SAVE=0 selects the instance without (parity tests run both).
 int zyzl_saved_layers(const cpf_plan* plan, int lw, int rot, int nslot) {
     const int LL = (int)plan->layer_ud.size() / 2;
-    if (lw != 0 || plan->NQ != 4 || nslot != 1 || LL < 1 || plan->K % LL != 0 || plan->K / LL < CPF_ZYZL_AOT_SAVE) return 0;
+    if (lw != 0 || plan->NQ != 4 || nslot != 1 || LL < 1 || plan->K % LL != 0 || plan->K / LL < CPF_ZYZL_AOT_SAVE + CPF_ZYZL_AOT_SAVEL) return 0;
     { const TuneVal e = tuning("CPF_ZYZL_SAVE"); if (e && e[0] == '0') return 0; }
-    return cpf_zyzl_has_aot(plan->NQ, rot, nslot + 16 * CPF_ZYZL_AOT_SAVE, plan->layer_ud) ? CPF_ZYZL_AOT_SAVE : 0;
+    return cpf_zyzl_has_aot(plan->NQ, rot, CPF_ZYZL_AOT_KEPT_CODE, plan->layer_ud) ? CPF_ZYZL_AOT_SAVE : 0;
 }
 bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStream_t stream, int* rc) {
     if (!zyzl_wanted(plan, a_in.mode, lw)) return false;
     const int nq = plan->NQ, rot = dense_rot_code(plan), which = labelling_for(plan, a_in.mode, lw);
-    const int nslot1 = zyzl_slots(plan, lw), save = zyzl_saved_layers(plan, lw, rot, nslot1), nslot = nslot1 + 16 * save;
+    const int nslot1 = zyzl_slots(plan, lw), save = zyzl_saved_layers(plan, lw, rot, nslot1), nslot = save ? CPF_ZYZL_AOT_KEPT_CODE : nslot1;
+    const int keptl_states = save ? CPF_ZYZL_AOT_SAVEL * (int)(plan->layer_ud.size() / 2) : 0;
     const bool have_aot = lw == 0 && cpf_zyzl_has_aot(nq, rot, nslot, plan->layer_ud);
     const cpf_jit::Kernel* jk = nullptr;
     if (!have_aot) {
@@ -650,7 +652,7 @@ bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStre
             return false;
         }
     }
-    const size_t lds1 = (size_t)cpf::ZyzlLds(plan->K, nq, 1 << lw).total * sizeof(float);
+    const size_t lds1 = (size_t)cpf::ZyzlLds(plan->K, nq, 1 << lw, keptl_states).total * sizeof(float);
     if (lds1 > (size_t)plan->lds_per_cu) return false;
     cpf::KArgs a = a_in;
     a.group = lw == 0 ? layered_group(plan, lw, S, lds1) : 1;
@@ -663,7 +665,7 @@ bool try_zyzl(cpf_plan* plan, const cpf::KArgs& a_in, int lw, int64_t S, hipStre
     const std::string tail = " waves=" + std::to_string(1 << lw) + (a.group > 1 ? " group=" + std::to_string(a.group) : "");
     if (have_aot) {
         cpf_zyzl_launch_aot(nq, rot, nslot, plan->layer_ud, za, grid, block, lds, stream, &e);
-        plan->variant = "zyzl/aot" + tail + (save ? " kept=" + std::to_string(save) : "");
+        plan->variant = "zyzl/aot" + tail + (save ? " kept=" + std::to_string(save) + (CPF_ZYZL_AOT_SAVEL ? "+" + std::to_string(CPF_ZYZL_AOT_SAVEL) : std::string()) : "");
     } else {
         if (!module_lds_opt_in(jk->fn, lds)) { plan->jit_note = "dynamic LDS opt-in refused for the ZYZ-form kernel"; return false; }
         cpf::ZyzlArgs args = za;

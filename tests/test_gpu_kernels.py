@@ -873,10 +873,10 @@ def test_zyz_form_gradient_at_degenerate_angles(tune):
 ZYZL_CASES = [
     # (layer, K, rot, entangler, ahead-of-time instance / run-time build)
     ([[0, 1], [1, 2], [2, 3]], 10, 'xyz', 'cp', 'aot'),                      # config 4's layer (relabelled by the plan): lane + register, register + register
-    ([[0, 1], [1, 2], [2, 3]], 24, 'xyz', 'cp', 'aot'),                      # config 4's block count: the last 5 of its 8 layers keep their input states
-    ([[0, 1], [1, 2], [2, 3]], 15, 'xyz', 'cp', 'aot'),                      # exactly 5 layers: every block's input state kept, nothing un-applied from psi
-    ([[0, 1], [1, 2], [2, 3]], 18, 'xyz', 'cp', 'aot'),                      # one layer un-applied behind five kept ones
-    ([[0, 1], [1, 2], [2, 3]], 12, 'xyz', 'cp', 'aot'),                      # four layers: below the kept-states instance's five
+    ([[0, 1], [1, 2], [2, 3]], 24, 'xyz', 'cp', 'aot'),                      # config 4's block count: the last 2 of its 8 layers keep their blocks' input states in registers
+    ([[0, 1], [1, 2], [2, 3]], 6, 'xyz', 'cp', 'aot'),                       # exactly 2 layers: every block's input state kept, nothing un-applied from psi
+    ([[0, 1], [1, 2], [2, 3]], 9, 'xyz', 'cp', 'aot'),                       # one layer un-applied behind the two kept ones
+    ([[0, 1], [1, 2], [2, 3]], 3, 'xyz', 'cp', 'aot'),                       # one layer: below the kept-states instance's two
     ([[0, 1], [0, 2], [0, 3]], 8, 'xyz', 'cp', 'jit'),                       # 4-qubit star (tutorial/results/toff4_star)
     ([[3, 0], [0, 2], [0, 1], [2, 1]], 9, 'xz', 'cp', 'jit'),                # twisted placements, two letters
     ([[0, 1], [1, 2], [2, 3], [3, 4]], 11, 'xyz', 'cp', 'jit'),              # 5 qubits: 16 amplitudes per lane, one lane qubit
