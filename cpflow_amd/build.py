@@ -87,7 +87,7 @@ def precompile_shapes():
     shapes += [(layer, 'xyz', K, 1000, 'cz') for layer in (conn3, chain3) for K in (2, 4, 6, 8, 10, 12, 14, 16)]
     # 3 qubits, the block counts an adaptive search over the reference's layers visits (tutorial/results/toff3_chain:
     # 10..20): the two-ended ZYZ-form kernel (cpf_zyz3.h) is specialised on block count, cut and layer, and
-    # cpf_jit_precompile builds all three launch regimes' cuts of a shape whatever the sample count named here, so one
+    # cpf_jit_precompile builds all four launch regimes' cuts of a shape whatever the sample count named here, so one
     # entry per shape ships everything a launch of that shape can ask for (nothing compiles on a GPU box).  A few
     # seconds of hipcc each.  (The 'cz' template shapes of the local-minimum study are in the list above.)
     shapes += [(layer, rot, K, 1000, 'cp') for layer in (chain3, conn3) for rot in ('xyz', 'xz') for K in range(6, 25)]
